@@ -1,0 +1,260 @@
+/* zr_capi.h — C ABI of the MI355X path-tracing integrator ("zr" = Zenith replacement).
+ *
+ * The reference (jarek1992/raytracer_project) has no FFI: its seam is the C++ virtual API
+ *   hittable::hit / bounding_box          /root/reference/hittable.hpp:29-36
+ *   material::scatter / emitted           /root/reference/material.hpp:7-31
+ *   texture::value                        /root/reference/texture.hpp:6-10
+ *   camera::render(world, env, post, flag) /root/reference/camera.hpp:236
+ * and its objects keep all data private.  The drop-in therefore has two layers:
+ *   (1) include/zenith/ — C++20 classes with the reference's names, constructors and signatures whose
+ *       camera::render() flattens the world and calls
+ *   (2) this C ABI — plain pointers and sizes, no C++ or torch types — implemented by
+ *       raytracer_project_amd/csrc (libzr_hip.so).  It is what a cgo/JNI/ctypes binding would bind.
+ *
+ * Every entry point names the reference interface it replaces.  All arithmetic on the path is FP64,
+ * as in the reference (vec3 is 3 x double, /root/reference/vec3.hpp:7-115).
+ *
+ * Ownership: every pointer is caller-owned; the library copies on set_*.  A zr_ctx is bound to one HIP
+ * device and must be used from one host thread at a time.  Functions returning int return 0 on
+ * success and a negative ZR_E_* code otherwise; zr_last_error() describes the last failure of the
+ * calling thread.  Nothing throws across this boundary.
+ */
+#ifndef ZR_CAPI_H
+#define ZR_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZR_ABI_VERSION 1
+
+enum {
+    ZR_OK = 0,
+    ZR_E_INVALID = -1,  /* bad argument / inconsistent scene */
+    ZR_E_DEVICE = -2,   /* HIP runtime error (no device, launch failure, out of memory) */
+    ZR_E_STATE = -3,    /* call order violated (e.g. render before commit) */
+    ZR_E_CANCELLED = -4 /* render_flag went false; partial results were written */
+};
+
+/* ---- primitive / object kinds ------------------------------------------------------------- */
+enum {
+    ZR_PRIM_SPHERE = 0,   /* sphere            /root/reference/sphere.hpp:5-89 */
+    ZR_PRIM_TRIANGLE = 1, /* triangle          /root/reference/triangle.hpp:5-110 */
+    ZR_PRIM_CUBE = 2,     /* cube              /root/reference/cube.hpp:7-143 */
+    ZR_PRIM_MEDIUM = 3    /* constant_medium   /root/reference/constant_medium.hpp:24-87 */
+};
+
+/* instance wrappers (applied outermost first to the ray, innermost first to the hit record) */
+enum {
+    ZR_OP_TRANSLATE = 0, /* translate          /root/reference/translate.hpp:6-41   a = offset */
+    ZR_OP_ROTATE_X = 1,  /* rotate_x (degrees) /root/reference/rotate_x.hpp:7-80    a[0]=sin a[1]=cos */
+    ZR_OP_ROTATE_Y = 2,  /* rotate_y (radians) /root/reference/rotate_y.hpp:7-83    a[0]=sin a[1]=cos */
+    ZR_OP_ROTATE_Z = 3,  /* rotate_z (degrees) /root/reference/rotate_z.hpp:7-77    a[0]=sin a[1]=cos */
+    ZR_OP_SCALE = 4,     /* scale              /root/reference/scale.hpp:5-45       a = factors */
+    ZR_OP_MATERIAL = 5   /* material_instance  /root/reference/material_instance.hpp:5-41  mat = id */
+};
+
+typedef struct zr_xform_op {
+    uint32_t kind; /* ZR_OP_* */
+    uint32_t mat;  /* ZR_OP_MATERIAL: material id */
+    double a[3];
+} zr_xform_op;
+
+/* one entry of the world list (what hittable_list::add received, hittable_list.hpp:24-27) */
+typedef struct zr_object {
+    uint32_t type;        /* ZR_PRIM_* */
+    uint32_t index;       /* index into that type's array */
+    uint32_t chain_first; /* first wrapper op (outermost) in the op array */
+    uint32_t chain_count; /* number of wrapper ops, 0 = bare primitive */
+} zr_object;
+
+/* constant_medium(boundary, density, tex|color): boundary is a sphere or cube entry that is not
+ * itself part of the world list; `mat` is the id of a ZR_MAT_ISOTROPIC material. */
+typedef struct zr_medium {
+    uint32_t boundary_type;  /* ZR_PRIM_SPHERE or ZR_PRIM_CUBE */
+    uint32_t boundary_index;
+    uint32_t chain_first;    /* wrappers applied to the boundary (inside the medium) */
+    uint32_t chain_count;
+    uint32_t mat;
+    uint32_t pad_;
+    double neg_inv_density;  /* -1/density, constant_medium.hpp:30,37 */
+} zr_medium;
+
+/* ---- materials and textures --------------------------------------------------------------- */
+enum {
+    ZR_MAT_LAMBERTIAN = 0, /* material.hpp:58-108 */
+    ZR_MAT_METAL = 1,      /* material.hpp:111-163   param = fuzz (already clamped to <= 1) */
+    ZR_MAT_DIELECTRIC = 2, /* material.hpp:166-242   param = refraction index, tint = albedo colour */
+    ZR_MAT_LIGHT = 3,      /* diffuse_light, material.hpp:245-279 */
+    ZR_MAT_ISOTROPIC = 4   /* isovolumetric, constant_medium.hpp:9-22 */
+};
+
+#define ZR_NO_TEXTURE 0xFFFFFFFFu
+
+typedef struct zr_material {
+    uint32_t kind;          /* ZR_MAT_* */
+    uint32_t tex;           /* albedo / emission texture id (unused by dielectric) */
+    uint32_t bump_tex;      /* bump map texture id or ZR_NO_TEXTURE (material.hpp:35-54) */
+    uint32_t pad_;
+    double param;           /* fuzz or refraction index */
+    double bump_strength;
+    double tint[3];         /* dielectric albedo */
+} zr_material;
+
+enum {
+    ZR_TEX_SOLID = 0,     /* solid_color     texture.hpp:86-102 */
+    ZR_TEX_CHECKER = 1,   /* checker_texture texture.hpp:104-133 */
+    ZR_TEX_IMAGE_U8 = 2,  /* image_texture, 8-bit RGB   texture.hpp:12-84 */
+    ZR_TEX_IMAGE_F32 = 3  /* image_texture, float RGB (HDR) */
+};
+
+typedef struct zr_texture {
+    uint32_t kind;      /* ZR_TEX_* */
+    uint32_t odd, even; /* checker: child texture ids */
+    uint32_t width, height; /* image; 0 x 0 = the reference's "missing image" cyan fallback */
+    uint32_t pad_;
+    uint64_t texel_offset;  /* byte offset of the first texel inside the texel blob */
+    double inv_scale;       /* checker */
+    double color[3];        /* solid */
+} zr_texture;
+
+/* ---- environment: EnvironmentSettings, /root/reference/environment.hpp:8-76 ---------------- */
+enum { ZR_ENV_PHYSICAL_SUN = 0, ZR_ENV_HDR_MAP = 1, ZR_ENV_SOLID_COLOR = 2 };
+
+typedef struct zr_env {
+    uint32_t mode;        /* ZR_ENV_* (same order as EnvironmentSettings::Mode) */
+    uint32_t hdr_texture; /* texture id of an IMAGE_F32 texture, or ZR_NO_TEXTURE */
+    double background_color[3];
+    double intensity;
+    double hdri_rotation, hdri_tilt, hdri_roll; /* radians */
+    double sun_direction[3];
+    double sun_color[3];
+    double sun_intensity;
+    double sun_size;
+} zr_env;
+
+/* ---- camera: the public fields camera::render reads, /root/reference/camera.hpp:26-57 ------- */
+typedef struct zr_camera {
+    int32_t image_width, image_height;
+    int32_t samples_per_pixel;
+    int32_t max_depth;
+    double vfov;
+    double lookfrom[3], lookat[3], vup[3];
+    double defocus_angle;
+    double focus_dist;
+} zr_camera;
+
+/* which part of the frame one call renders.  Pixels are visited in 2-D tiles of tile_size x tile_size;
+ * tile t (row-major tile index) is rendered iff t % tile_mod == tile_rem — the interleaved pixel-tile
+ * sharding across GPUs.  The rectangle [x0,x0+w) x [y0,y0+h) further restricts the
+ * pixels (used by parity tests); w = h = 0 means the full frame. */
+typedef struct zr_region {
+    int32_t x0, y0, w, h;
+    int32_t tile_size; /* 0 = default (32) */
+    int32_t tile_mod;  /* 0 or 1 = every tile */
+    int32_t tile_rem;
+    int32_t pad_;
+} zr_region;
+
+/* counters of the last zr_render on a context (collected only when `collect_counters` was set:
+ * the counting kernel variant is slower and is never the timed one) */
+typedef struct zr_counters {
+    uint64_t primary_samples;
+    uint64_t segments;       /* closest-hit queries = "ray·bounces" */
+    uint64_t nodes_tested;   /* BVH child boxes tested */
+    uint64_t spheres_tested;
+    uint64_t triangles_tested;
+    uint64_t cubes_tested;
+    uint64_t media_tested;
+    uint64_t hits;           /* segments that found a surface / medium event */
+    uint64_t rng_draws;      /* main-stream draws */
+    double kernel_ms;        /* device time of the render kernels of the last call (hipEvents) */
+} zr_counters;
+
+/* hit record returned by zr_trace (debug / known-answer entry): hit_record, hittable.hpp:9-26 */
+typedef struct zr_hit {
+    double p[3], normal[3], tangent[3], bitangent[3];
+    double t, u, v;
+    uint32_t mat;       /* material id, 0xFFFFFFFF on a miss */
+    uint32_t front_face;
+} zr_hit;
+
+/* a whole flattened world as borrowed arrays (layouts as in the zr_scene_set_* calls below) */
+typedef struct zr_scene_desc {
+    const double* spheres;      const uint32_t* sphere_mat;   uint64_t n_spheres;
+    const double* tri_v;        const double* tri_n;          const uint32_t* tri_mat; uint64_t n_tris;
+    const double* cubes;        const uint32_t* cube_mat;     uint64_t n_cubes;
+    const zr_medium* media;     uint64_t n_media;
+    const zr_xform_op* ops;     uint64_t n_ops;
+    const zr_object* objects;   uint64_t n_objects; /* 0 = implicit world list */
+    const zr_material* materials; uint64_t n_materials;
+    const zr_texture* textures; uint64_t n_textures;
+    const void* texels;         uint64_t texel_bytes;
+} zr_scene_desc;
+
+typedef struct zr_ctx zr_ctx;
+typedef struct zr_scene zr_scene;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+int zr_abi_version(void);
+const char* zr_last_error(void);
+zr_ctx* zr_create(int device_ordinal); /* NULL on failure (no HIP device => fails loudly) */
+void zr_destroy(zr_ctx*);
+
+/* ---- scene: replaces building a hittable_list / bvh_node of reference objects -------------- */
+zr_scene* zr_scene_create(zr_ctx*);
+void zr_scene_destroy(zr_scene*);
+/* sphere(center, radius, mat): 4 doubles per sphere = cx, cy, cz, radius (raw ctor argument) */
+int zr_scene_set_spheres(zr_scene*, const double* cxyz_r, const uint32_t* mat, size_t n);
+/* triangle(a,b,c,n0,n1,n2,mat): 9 doubles of vertices, 9 doubles of vertex normals */
+int zr_scene_set_triangles(zr_scene*, const double* v9, const double* n9, const uint32_t* mat, size_t n);
+/* cube: 12 doubles = half_extents, center, min_p, max_p exactly as the cube members (cube.hpp:92-97) */
+int zr_scene_set_cubes(zr_scene*, const double* hcmm12, const uint32_t* mat, size_t n);
+int zr_scene_set_media(zr_scene*, const zr_medium*, size_t n);
+int zr_scene_set_xform_ops(zr_scene*, const zr_xform_op*, size_t n);
+/* the world list.  If never called, every sphere/triangle/cube/medium that is not a medium boundary
+ * is a bare top-level object. */
+int zr_scene_set_objects(zr_scene*, const zr_object*, size_t n);
+int zr_scene_set_materials(zr_scene*, const zr_material*, size_t n);
+int zr_scene_set_textures(zr_scene*, const zr_texture*, size_t n, const void* texel_blob, size_t texel_bytes);
+/* all of the above in one call */
+int zr_scene_set_all(zr_scene*, const zr_scene_desc*);
+/* builds the flattened BVH (replaces bvh_node's constructor, bvh.hpp:11-44) and uploads to HBM */
+int zr_scene_commit(zr_scene*);
+/* sizes of the committed scene: out[0]=bvh nodes (child-pair records), [1]=max depth, [2]=objects,
+ * [3]=device bytes */
+int zr_scene_stats(const zr_scene*, uint64_t out[4]);
+
+/* ---- render: replaces camera::render's sample loop (camera.hpp:236-248, 404-579) ----------- */
+/* Fills out_rgb[(j*W+i)*3 + c] (host memory, W*H*3 doubles, row 0 = top, mean over spp — the layout of
+ * camera::render_accumulator) for the pixels of `region`; other pixels are left untouched.
+ * `keep_going` (may be NULL) is polled between kernel batches and has render_flag's polarity
+ * (camera.hpp:441): *keep_going == 0 stops the render (ZR_E_CANCELLED, finished batches are written).
+ * `rows_done` (may be NULL) is advanced like camera::lines_rendered and set to H at the end. */
+int zr_render(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed,
+              const zr_region* region, int collect_counters,
+              double* out_rgb, volatile const uint8_t* keep_going, volatile int* rows_done);
+/* Same, but the accumulator stays in HBM: d_out_rgb is a device pointer to W*H*3 doubles and the work
+ * is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.  This is
+ * what the multi-GPU host uses before the RCCL reduce. */
+int zr_render_device(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed,
+                     const zr_region* region, int collect_counters,
+                     void* d_out_rgb, void* hip_stream);
+/* counters + device time of the last render on this context (synchronises the context's stream) */
+int zr_get_counters(zr_ctx*, zr_counters*);
+/* device time (ms) of each of the last `cap` render-kernel launches, newest last; returns the count */
+int zr_get_kernel_times(zr_ctx*, float* ms, int cap);
+
+/* ---- known-answer entry: world.hit(r, interval(tmin,tmax), rec) for a batch of rays ---------- */
+/* rays: 6 doubles each (origin, direction).  The medium draw of ray k (zr_rng.h) is keyed by
+ * zr_stream_key(seed, pixel, k) and `bounce`. */
+int zr_trace(zr_ctx*, const zr_scene*, const double* rays6, size_t n, double tmin, double tmax,
+             uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZR_CAPI_H */

@@ -1,0 +1,469 @@
+// ref_harness.cpp — TEST INFRASTRUCTURE (oracle).  Never shipped, never on the product path.
+//
+// Drives the GENUINE reference arithmetic from /root/reference (headers are #included by path at build
+// time, in this container only; nothing of them is copied into the repo):
+//   world.hit          bvh.hpp:46-54,112-118  aabb.hpp:44-66  sphere.hpp:18-64  triangle.hpp:17-82
+//                      cube.hpp:44-142  constant_medium.hpp:39-77  translate/rotate_*/scale/material_instance
+//   scatter / emitted  material.hpp:74-96,129-151,192-224,261-263  constant_medium.hpp:14-18
+//   texture::value     texture.hpp:50-78,96-98,118-126
+//   random_double() and the rejection samplers  common.hpp:29-44  vec3.hpp:174-191
+//
+// What is NOT the genuine code: camera.hpp cannot be compiled in this image — it includes
+// <OpenImageDenoise/oidn.hpp> (camera.hpp:10), a library that is absent — so the camera set-up, the ray
+// generator, the background and the bounce loop are RESTATED below (struct ref_camera), following
+// camera.hpp:358-402 (initialize), 784-825 (get_ray), 828-925 (get_background_color),
+// 928-986 (ray_color), 989-1004 (ray_color_from_hit) and the beauty part of render_rows 454-531,
+// on the reference's own vec3/ray/hittable/material/EnvironmentSettings types.
+//
+// Determinism: ref_prelude.hpp injects the counter engine of include/zr_rng.h in place of the
+// reference's racy global mt19937.  Build with ROCm clang++ (left-to-right argument evaluation, the
+// same front end as hipcc): see oracle/Makefile.
+#include "ref_prelude.hpp"
+
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+
+#include "../include/zr_capi.h"
+
+// ---- genuine reference headers (order as main.cpp:7-13 needs it) -----------------------------
+#include "common.hpp"
+#include "hittable.hpp"
+#include "texture.hpp"
+#include "material.hpp"
+#include "hittable_list.hpp"
+#include "sphere.hpp"
+#include "triangle.hpp"
+#include "cube.hpp"
+#include "constant_medium.hpp"
+#include "translate.hpp"
+#include "rotate_x.hpp"
+#include "rotate_y.hpp"
+#include "rotate_z.hpp"
+#include "scale.hpp"
+#include "material_instance.hpp"
+#include "bvh.hpp"
+#include "environment.hpp"
+
+// ---- hooks for scenes/zr_scenes.inc ------------------------------------------------------------
+static void zr_hook_seed_scene(uint64_t seed, uint64_t stream) { zr_oracle_seed(seed, ZR_SCENE_PIXEL, stream); }
+
+// tags a constant_medium with its id so that the draw inside constant_medium::hit is keyed off-stream
+class keyed_medium : public hittable {
+public:
+    keyed_medium(shared_ptr<hittable> m, uint32_t id) : inner(m), id(id) {}
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int depth = 0, bool debug_wire = false) const override {
+        zr_oracle_tls_t& s = zr_oracle_tls;
+        s.in_medium = true; s.medium_id = id;
+        bool h = inner->hit(r, ray_t, rec, depth, debug_wire);
+        s.in_medium = false;
+        return h;
+    }
+    aabb bounding_box() const override { return inner->bounding_box(); }
+private:
+    shared_ptr<hittable> inner; uint32_t id;
+};
+static uint32_t g_next_medium_id = 0;
+static shared_ptr<hittable> zr_hook_medium(shared_ptr<hittable> m) { return make_shared<keyed_medium>(m, g_next_medium_id++); }
+
+#include "../scenes/zr_scenes.inc"
+#include "../scenes/zr_scenes_mix.inc"
+
+// counts closest-hit queries ("segments") and publishes the bounce index for the medium key
+struct seg_tls_t { uint64_t segments = 0; };
+static thread_local seg_tls_t seg_tls;
+class probe_world : public hittable {
+public:
+    explicit probe_world(const hittable& w) : w(w) {}
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int depth = 0, bool debug_wire = false) const override {
+        zr_oracle_tls.bounce = (uint32_t)seg_in_sample();
+        seg_tls.segments++;
+        sample_segments()++;
+        return w.hit(r, ray_t, rec, depth, debug_wire);
+    }
+    aabb bounding_box() const override { return w.bounding_box(); }
+    static uint64_t& sample_segments() { static thread_local uint64_t n = 0; return n; }
+    static uint64_t seg_in_sample() { return sample_segments(); }
+private:
+    const hittable& w;
+};
+
+// ---- restated camera (see header comment) ------------------------------------------------------
+struct ref_camera {
+    zr_camera c;
+    point3 center, pixel00;
+    vec3 du, dv, u, v, w, disk_u, disk_v;
+
+    void initialize() {  // camera.hpp:358-399
+        if (c.image_width < 1) c.image_width = 1;
+        if (c.image_height < 1) c.image_height = 1;
+        double aspect = double(c.image_width) / c.image_height;
+        center = point3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
+        point3 at(c.lookat[0], c.lookat[1], c.lookat[2]);
+        vec3 up(c.vup[0], c.vup[1], c.vup[2]);
+        double theta = degrees_to_radians(c.vfov);
+        double h = std::tan(theta / 2);
+        double vh = 2 * h * c.focus_dist;
+        double vw = vh * aspect;
+        w = unit_vector(center - at);
+        u = unit_vector(cross(up, w));
+        v = cross(w, u);
+        vec3 vu = vw * u;
+        vec3 vv = vh * -v;
+        du = vu / c.image_width;
+        dv = vv / c.image_height;
+        point3 ul = center - (c.focus_dist * w) - vu / 2 - vv / 2;
+        pixel00 = ul + 0.5 * (du + dv);
+        double rad = c.focus_dist * std::tan(degrees_to_radians(c.defocus_angle / 2));
+        disk_u = u * rad;
+        disk_v = v * rad;
+    }
+
+    ray get_ray(int i, int j) const {  // camera.hpp:784-794, 817-825
+        double ox = random_double() - 0.5;  // sample_square: x drawn first (left-to-right build)
+        double oy = random_double() - 0.5;
+        point3 ps = pixel00 + ((i + ox) * du) + ((j + oy) * dv);
+        point3 org = center;
+        if (!(c.defocus_angle <= 0)) {
+            vec3 p = random_in_unit_disk();
+            org = center + (p[0] * disk_u) + (p[1] * disk_v);
+        }
+        return ray(org, ps - org);
+    }
+
+    color background(const ray& r, const EnvironmentSettings& env) const {  // camera.hpp:828-925
+        vec3 ud = unit_vector(r.direction());
+        if (env._mode == EnvironmentSettings::SOLID_COLOR) return env.background_color * env.intensity;
+        if (env._mode == EnvironmentSettings::HDR_MAP) {
+            if (!env.hdr_texture) return color(0, 0, 0);
+            vec3 d = ud;
+            double cy = cos(env.hdri_rotation), sy = sin(env.hdri_rotation);
+            double x1 = cy * d.x() + sy * d.z();
+            double z1 = -sy * d.x() + cy * d.z();
+            d = vec3(x1, d.y(), z1);
+            double cp = cos(env.hdri_tilt), sp = sin(env.hdri_tilt);
+            double y2 = cp * d.y() - sp * d.z();
+            double z2 = sp * d.y() + cp * d.z();
+            d = vec3(d.x(), y2, z2);
+            double cr = cos(env.hdri_roll), sr = sin(env.hdri_roll);
+            double x3 = cr * d.x() - sr * d.y();
+            double y3 = sr * d.x() + cr * d.y();
+            d = vec3(x3, y3, d.z());
+            double phi = atan2(d.z(), d.x()) + pi;
+            double theta = acos(std::clamp(d.y(), -1.0, 1.0));
+            return env.hdr_texture->value(phi / (2 * pi), theta / pi, point3(0, 0, 0)) * env.intensity;
+        }
+        vec3 sun = unit_vector(env.sun_direction);
+        double sh = sun.y();
+        double ah = sh - 0.05;
+        double sky_exposure = std::clamp(ah * 8.0 + 1.4, 0.0, 1.0);
+        double day = std::clamp(ah * 10.0 + 1.1, 0.0, 1.0);
+        double sunset_i = std::clamp(1.0 - std::abs(ah + 0.05) * 30.0, 0.0, 1.0);
+        double sunset = (ah > -0.1) ? sunset_i : 0.0;
+        if (sh < 0) sunset *= (sh * 10.0 + 1.0);
+        sunset = std::clamp(sunset, 0.0, 1.0);
+        color zen = color(0.01, 0.03, 0.1) * (1.0 - day) + color(0.2, 0.5, 1.0) * day;
+        color hor = color(0.05, 0.02, 0.01) * (1.0 - day) + color(0.6, 0.8, 1.0) * day;
+        hor = hor * (1.0 - sunset) + color(1.0, 0.35, 0.1) * sunset;
+        double a = ud.y();
+        color sky;
+        if (a > 0.0) sky = (1.0 - a) * hor + a * zen; else sky = hor * 0.1;
+        color fin = sky * (env.intensity * 1.5) * sky_exposure;
+        double focus = dot(ud, sun);
+        double thr = 1.0 - (env.sun_size * 0.001);
+        if (focus > thr && ah > -0.1) {
+            color sc = env.sun_color * (1.0 - sunset) + color(1.0, 0.3, 0.1) * sunset;
+            double vis = std::clamp(sh * 5.0 + 1.0, 0.0, 1.0);
+            double alpha = smoothstep(thr, thr + 0.0002, focus);
+            fin += sc * env.sun_intensity * vis * alpha;
+        }
+        return fin;
+    }
+
+    color ray_color(const ray& r, const hittable& world, int depth, const EnvironmentSettings& env) const {
+        // camera.hpp:928-986 (bvh_debug_mode branches are out of scope)
+        color L(0, 0, 0), beta(1, 1, 1);
+        ray cur = r;
+        for (int i = 0; i < depth; i++) {
+            hit_record rec;
+            if (!world.hit(cur, interval(0.001, infinity), rec, 0, false)) return L + beta * background(cur, env);
+            color em = rec.mat->emitted(rec.u, rec.v, rec.p);
+            L += beta * em;
+            ray sc; color att;
+            if (rec.mat->scatter(cur, rec, att, sc)) {
+                beta *= att;
+                cur = sc;
+                if (i > 10 && beta.length() < 0.0001) break;
+            } else {
+                break;
+            }
+            if (i > 10) {
+                double p = std::max({beta.x(), beta.y(), beta.z()});
+                p = std::clamp(p, 0.05, 0.95);
+                if (random_double() > p) break;
+                beta /= p;
+            }
+        }
+        return L;
+    }
+
+    color ray_color_from_hit(const ray& r, const hit_record& first, const hittable& world, int depth,
+                             const EnvironmentSettings& env) const {  // camera.hpp:989-1004
+        color L = first.mat->emitted(first.u, first.v, first.p);
+        color beta(1, 1, 1);
+        ray sc; color att;
+        if (first.mat->scatter(r, first, att, sc)) {
+            beta *= att;
+            return L + beta * ray_color(sc, world, depth - 1, env);
+        }
+        return L;
+    }
+
+    // one primary sample of pixel (i, j): the body of the sample loop, camera.hpp:455-461,520
+    color sample(int i, int j, const hittable& world, const EnvironmentSettings& env) const {
+        ray r = get_ray(i, j);
+        hit_record rec;
+        if (world.hit(r, interval(0.001, infinity), rec)) return ray_color_from_hit(r, rec, world, c.max_depth, env);
+        return background(r, env);
+    }
+};
+
+// ---- tiny .npy writer --------------------------------------------------------------------------
+static void write_npy(const std::string& path, const char* descr, const std::vector<size_t>& shape, const void* data,
+                      size_t bytes) {
+    std::string sh = "(";
+    for (size_t k = 0; k < shape.size(); k++) { sh += std::to_string(shape[k]); sh += (shape.size() == 1 || k + 1 < shape.size()) ? "," : ""; }
+    sh += ")";
+    std::string hdr = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': " + sh + ", }";
+    size_t total = 10 + hdr.size() + 1;
+    size_t pad = (64 - total % 64) % 64;
+    hdr += std::string(pad, ' ');
+    hdr += "\n";
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(2); }
+    unsigned char magic[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(hdr.size() & 255), (unsigned char)(hdr.size() >> 8)};
+    std::fwrite(magic, 1, 10, f);
+    std::fwrite(hdr.data(), 1, hdr.size(), f);
+    std::fwrite(data, 1, bytes, f);
+    std::fclose(f);
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct built_scene {
+    zr_demo_scene s;
+    shared_ptr<hittable> bvh;
+    double build_s = 0;
+};
+
+static bool build(built_scene& b, const std::string& name, int a0, int a1, int a2, int a3) {
+    g_next_medium_id = 0;
+    bool ok = zr_build_scene(name, b.s, a0, a1, a2, a3) || zr_build_scene_mix(name, b.s);
+    if (!ok) return false;
+    // bvh_node's constructor draws random_int(0,2) per node (bvh.hpp:17): give it its own scene stream
+    zr_oracle_seed(b.s.seed, ZR_SCENE_PIXEL, 1);
+    double t0 = now_s();
+    b.bvh = make_shared<bvh_node>(b.s.world);
+    b.build_s = now_s() - t0;
+    return true;
+}
+
+static void cleanup(built_scene& b) { for (auto& f : b.s.temp_files) ::unlink(f.c_str()); }
+
+// render [x0,x0+w) x [y0,y0+h) with `threads` row-interleaved host threads.
+// out: mean radiance (h*w*3 doubles); optional per-sample radiance and per-sample draw/segment counts.
+struct tile_result { uint64_t segments = 0, draws = 0, medium_draws = 0; double seconds = 0; };
+static tile_result render_tile(const built_scene& b, ref_camera cam, int x0, int y0, int w, int h, int spp, int threads,
+                               int xstep, int ystep, std::vector<double>& mean, std::vector<double>* per_sample,
+                               std::vector<uint32_t>* per_sample_counts) {
+    cam.c.samples_per_pixel = spp;
+    cam.initialize();
+    const int W = cam.c.image_width;
+    mean.assign((size_t)w * h * 3, 0.0);
+    if (per_sample) per_sample->assign((size_t)w * h * spp * 3, 0.0);
+    if (per_sample_counts) per_sample_counts->assign((size_t)w * h * spp * 2, 0);
+    probe_world world(*b.bvh);
+    std::atomic<uint64_t> segs{0}, draws{0}, mdraws{0};
+    std::atomic<int> next_row{0};
+    double t0 = now_s();
+    auto worker = [&]() {
+        seg_tls.segments = 0; zr_oracle_tls.draws = 0; zr_oracle_tls.medium_draws = 0;
+        for (;;) {
+            int jj = next_row.fetch_add(1);
+            if (jj >= h) break;
+            int j = y0 + jj * ystep;
+            for (int ii = 0; ii < w; ii++) {
+                int i = x0 + ii * xstep;
+                color acc(0, 0, 0);
+                for (int s = 0; s < spp; s++) {
+                    zr_oracle_seed(b.s.seed, (uint64_t)j * W + i, (uint64_t)s);
+                    probe_world::sample_segments() = 0;
+                    uint64_t d0 = zr_oracle_tls.draws;
+                    color c = cam.sample(i, j, world, b.s.env);
+                    acc += c;
+                    if (per_sample) {
+                        double* o = &(*per_sample)[(((size_t)jj * w + ii) * spp + s) * 3];
+                        o[0] = c.x(); o[1] = c.y(); o[2] = c.z();
+                    }
+                    if (per_sample_counts) {
+                        uint32_t* o = &(*per_sample_counts)[(((size_t)jj * w + ii) * spp + s) * 2];
+                        o[0] = (uint32_t)probe_world::sample_segments();
+                        o[1] = (uint32_t)(zr_oracle_tls.draws - d0);
+                    }
+                }
+                color m = acc * (1.0 / spp);  // camera.hpp:436-437,531 (light_scale)
+                double* o = &mean[((size_t)jj * w + ii) * 3];
+                o[0] = m.x(); o[1] = m.y(); o[2] = m.z();
+            }
+        }
+        segs += seg_tls.segments; draws += zr_oracle_tls.draws; mdraws += zr_oracle_tls.medium_draws;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    tile_result r;
+    r.seconds = now_s() - t0; r.segments = segs; r.draws = draws; r.medium_draws = mdraws;
+    return r;
+}
+
+static int usage() {
+    std::fprintf(stderr,
+                 "usage:\n"
+                 "  zenith_ref tile   <scene> <x0> <y0> <w> <h> <spp|0> <threads> <out_prefix> [per_sample=0] [a0 a1 a2 a3]\n"
+                 "  zenith_ref time   <scene> <xstep> <ystep> <spp|0> <threads> [a0 a1 a2 a3]\n"
+                 "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> [a0 a1 a2 a3]\n"
+                 "  zenith_ref texels <w> <h> <out.npy>\n");
+    return 2;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return usage();
+    std::string cmd = argv[1];
+    auto iarg = [&](int k, int dflt) { return argc > k ? std::atoi(argv[k]) : dflt; };
+
+    if (cmd == "tile" && argc >= 10) {
+        built_scene b;
+        if (!build(b, argv[2], iarg(11, 0), iarg(12, 0), iarg(13, 0), iarg(14, 0))) return usage();
+        int x0 = iarg(3, 0), y0 = iarg(4, 0), w = iarg(5, 1), h = iarg(6, 1), spp = iarg(7, 0), threads = iarg(8, 1);
+        std::string out = argv[9];
+        bool ps = iarg(10, 0) != 0;
+        ref_camera cam; cam.c = b.s.cam;
+        if (spp <= 0) spp = cam.c.samples_per_pixel;
+        std::vector<double> mean, per_sample; std::vector<uint32_t> counts;
+        tile_result r = render_tile(b, cam, x0, y0, w, h, spp, threads, 1, 1, mean, ps ? &per_sample : nullptr, ps ? &counts : nullptr);
+        write_npy(out + "_mean.npy", "<f8", {(size_t)h, (size_t)w, 3}, mean.data(), mean.size() * 8);
+        if (ps) {
+            write_npy(out + "_samples.npy", "<f8", {(size_t)h, (size_t)w, (size_t)spp, 3}, per_sample.data(), per_sample.size() * 8);
+            write_npy(out + "_counts.npy", "<u4", {(size_t)h, (size_t)w, (size_t)spp, 2}, counts.data(), counts.size() * 4);
+        }
+        std::printf("{\"scene\": \"%s\", \"x0\": %d, \"y0\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"max_depth\": %d, "
+                    "\"image_width\": %d, \"image_height\": %d, \"seed\": %llu, \"segments\": %llu, \"draws\": %llu, "
+                    "\"medium_draws\": %llu, \"objects\": %zu, \"bvh_build_s\": %.3f, \"render_s\": %.3f}\n",
+                    argv[2], x0, y0, w, h, spp, cam.c.max_depth, cam.c.image_width, cam.c.image_height,
+                    (unsigned long long)b.s.seed, (unsigned long long)r.segments, (unsigned long long)r.draws,
+                    (unsigned long long)r.medium_draws, b.s.world.objects.size(), b.build_s, r.seconds);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "time" && argc >= 7) {
+        // CPU baseline: every xstep-th column and ystep-th row of the full frame at `spp` samples
+        built_scene b;
+        if (!build(b, argv[2], iarg(7, 0), iarg(8, 0), iarg(9, 0), iarg(10, 0))) return usage();
+        int xstep = std::max(1, iarg(3, 1)), ystep = std::max(1, iarg(4, 1)), spp = iarg(5, 0), threads = std::max(1, iarg(6, 1));
+        ref_camera cam; cam.c = b.s.cam;
+        if (spp <= 0) spp = cam.c.samples_per_pixel;
+        int w = (cam.c.image_width + xstep - 1) / xstep, h = (cam.c.image_height + ystep - 1) / ystep;
+        std::vector<double> mean;
+        tile_result r = render_tile(b, cam, 0, 0, w, h, spp, threads, xstep, ystep, mean, nullptr, nullptr);
+        double sum = 0; for (double v : mean) sum += v;
+        std::printf("{\"scene\": \"%s\", \"pixels\": %d, \"spp\": %d, \"threads\": %d, \"segments\": %llu, \"primary\": %llu, "
+                    "\"render_s\": %.4f, \"mseg_per_s\": %.4f, \"bvh_build_s\": %.3f, \"objects\": %zu, \"checksum\": %.17g}\n",
+                    argv[2], w * h, spp, threads, (unsigned long long)r.segments, (unsigned long long)((uint64_t)w * h * spp),
+                    r.seconds, r.segments / r.seconds * 1e-6, b.build_s, b.s.world.objects.size(), sum);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "trace" && argc >= 6) {
+        // known answers of world.hit on random rays: rays aimed from a shell around the scene box
+        // towards points inside it, plus rays starting inside.  Record = hit_record fields.
+        built_scene b;
+        if (!build(b, argv[2], iarg(6, 0), iarg(7, 0), iarg(8, 0), iarg(9, 0))) return usage();
+        size_t n = (size_t)iarg(3, 1000);
+        uint64_t seed = (uint64_t)iarg(4, 1);
+        std::string out = argv[5];
+        aabb box = b.bvh->bounding_box();
+        auto clampf = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        // keep the probe region finite for scenes with a huge ground sphere
+        double lo[3] = {clampf(box.x.min, -30, 600), clampf(box.y.min, -30, 600), clampf(box.z.min, -30, 600)};
+        double hi[3] = {clampf(box.x.max, -30, 600), clampf(box.y.max, -30, 600), clampf(box.z.max, -30, 600)};
+        std::vector<double> rays(n * 6), recs(n * 16);
+        // map material pointers to first-seen ordinal so fixtures can compare material identity
+        std::map<const material*, int> mat_id;
+        probe_world world(*b.bvh);
+        for (size_t k = 0; k < n; k++) {
+            zr_oracle_seed(seed, 0x7ACEull, k);
+            double q[6]; for (double& v : q) v = random_double();
+            double o[3], t[3];
+            for (int c = 0; c < 3; c++) {
+                double ext = hi[c] - lo[c];
+                o[c] = lo[c] - 0.25 * ext + 1.5 * ext * q[c];
+                t[c] = lo[c] + ext * q[3 + c];
+            }
+            ray r(point3(o[0], o[1], o[2]), vec3(t[0] - o[0], t[1] - o[1], t[2] - o[2]));
+            hit_record rec;
+            probe_world::sample_segments() = 0;  // bounce 0 for the medium key
+            bool h = world.hit(r, interval(0.001, infinity), rec);
+            double* rr = &rays[k * 6];
+            rr[0] = o[0]; rr[1] = o[1]; rr[2] = o[2]; rr[3] = t[0] - o[0]; rr[4] = t[1] - o[1]; rr[5] = t[2] - o[2];
+            double* e = &recs[k * 16];
+            if (h) {
+                int id;
+                auto it = mat_id.find(rec.mat.get());
+                if (it == mat_id.end()) { id = (int)mat_id.size(); mat_id[rec.mat.get()] = id; } else id = it->second;
+                e[0] = 1; e[1] = rec.t; e[2] = rec.p.x(); e[3] = rec.p.y(); e[4] = rec.p.z();
+                e[5] = rec.normal.x(); e[6] = rec.normal.y(); e[7] = rec.normal.z();
+                e[8] = rec.front_face ? 1 : 0; e[9] = rec.u; e[10] = rec.v;
+                e[11] = rec.tangent.x(); e[12] = rec.tangent.y(); e[13] = rec.tangent.z();
+                e[14] = id;
+                // one scatter with the stream positioned at draw 0: attenuation checksum
+                ray sc; color att;
+                zr_oracle_tls.k = 0;
+                bool s = rec.mat->scatter(r, rec, att, sc);
+                e[15] = s ? (att.x() + 2 * att.y() + 4 * att.z()) : -1.0;
+            } else {
+                for (int c = 0; c < 16; c++) e[c] = 0;
+            }
+        }
+        write_npy(out + "_rays.npy", "<f8", {n, 6}, rays.data(), rays.size() * 8);
+        write_npy(out + "_recs.npy", "<f8", {n, 16}, recs.data(), recs.size() * 8);
+        std::printf("{\"scene\": \"%s\", \"rays\": %zu, \"seed\": %llu, \"stream_pixel\": %llu}\n", argv[2], n,
+                    (unsigned long long)seed, 0x7ACEull);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "texels" && argc >= 5) {
+        // decoded texels of the synthetic HDRI as the reference's stb loader returns them, sampled
+        // through image_texture::value at every texel centre (public API only)
+        int w = iarg(2, 64), h = iarg(3, 32);
+        std::string p = "/tmp/zr_texels_" + std::to_string((long)getpid()) + ".hdr";
+        zr_write_synthetic_hdr(p, w, h);
+        image_texture tex(p.c_str(), true);
+        std::vector<float> out((size_t)w * h * 3);
+        for (int j = 0; j < h; j++)
+            for (int i = 0; i < w; i++) {
+                color c = tex.value((i + 0.5) / w, (j + 0.5) / h, point3(0, 0, 0));
+                out[((size_t)j * w + i) * 3 + 0] = (float)c.x();
+                out[((size_t)j * w + i) * 3 + 1] = (float)c.y();
+                out[((size_t)j * w + i) * 3 + 2] = (float)c.z();
+            }
+        write_npy(argv[4], "<f4", {(size_t)h, (size_t)w, 3}, out.data(), out.size() * 4);
+        ::unlink(p.c_str());
+        return 0;
+    }
+    return usage();
+}

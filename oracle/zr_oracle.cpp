@@ -1,0 +1,862 @@
+// zr_oracle.cpp — TEST INFRASTRUCTURE: CPU restatement of the reference's per-pixel sample loop.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+// the checker.  The product (raytracer_project_amd/csrc, libzr_hip.so) never links or calls it.
+//
+// It restates, in plain scalar FP64 C++ with the reference's exact operation order (build with
+// -ffp-contract=off), on the flattened scene arrays of include/zr_capi.h:
+//   camera::initialize / get_ray / get_background_color / ray_color / ray_color_from_hit
+//                                   /root/reference/camera.hpp:358-399, 784-825, 828-925, 928-1004
+//   the beauty part of render_rows   camera.hpp:454-461, 520, 530-531
+//   sphere::hit + get_sphere_uv      sphere.hpp:18-79
+//   triangle::hit                    triangle.hpp:17-82
+//   cube::hit + set_cube_hit_data    cube.hpp:44-142
+//   constant_medium::hit, isovolumetric::scatter   constant_medium.hpp:14-18, 39-77
+//   translate/rotate_x/rotate_y/rotate_z/scale/material_instance ::hit  (files of the same names)
+//   lambertian/metal/dielectric/diffuse_light, get_bumped_normal   material.hpp:35-54,74-96,129-151,192-241,261-263
+//   solid_color/checker_texture/image_texture ::value               texture.hpp:50-78,96-98,118-126
+//   vec3 helpers (operator/ multiplies by the reciprocal!)           vec3.hpp:71-80,91-95,149-214
+//   interval::contains/surrounds, hit_record::set_face_normal         interval.hpp:39-44, hittable.hpp:22-25
+// Closest-hit search: brute force over the world list for small scenes, otherwise a private
+// median-split BVH (the reference's tree, bvh.hpp:11-44, is random-axis and not reproducible; closest
+// hit does not depend on the tree).  RNG: the contract of include/zr_rng.h.
+//
+// Pinned against the genuine reference by tests/test_oracle_golden.py (fixtures made by
+// oracle/_ref/zenith_ref via tests/golden/make_golden.py).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "zr_capi.h"
+#include "zr_rng.h"
+
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+const double kPi = 3.14159265358979323846;
+const double kRayEps = 0.0001;
+
+struct V3 {
+    double e[3];
+    V3() : e{0, 0, 0} {}
+    V3(double a, double b, double c) : e{a, b, c} {}
+    double x() const { return e[0]; }
+    double y() const { return e[1]; }
+    double z() const { return e[2]; }
+    double operator[](int i) const { return e[i]; }
+    double& operator[](int i) { return e[i]; }
+};
+inline V3 operator+(const V3& u, const V3& v) { return V3(u.e[0] + v.e[0], u.e[1] + v.e[1], u.e[2] + v.e[2]); }
+inline V3 operator-(const V3& u, const V3& v) { return V3(u.e[0] - v.e[0], u.e[1] - v.e[1], u.e[2] - v.e[2]); }
+inline V3 operator-(const V3& u) { return V3(-u.e[0], -u.e[1], -u.e[2]); }
+inline V3 operator*(const V3& u, const V3& v) { return V3(u.e[0] * v.e[0], u.e[1] * v.e[1], u.e[2] * v.e[2]); }
+inline V3 operator*(double t, const V3& v) { return V3(t * v.e[0], t * v.e[1], t * v.e[2]); }
+inline V3 operator*(const V3& v, double t) { return t * v; }
+inline V3 operator/(const V3& v, double t) { return (1 / t) * v; }  // vec3.hpp:149-151: reciprocal multiply
+inline double dot(const V3& u, const V3& v) { return u.e[0] * v.e[0] + u.e[1] * v.e[1] + u.e[2] * v.e[2]; }
+inline V3 cross(const V3& u, const V3& v) {
+    return V3(u.e[1] * v.e[2] - u.e[2] * v.e[1], u.e[2] * v.e[0] - u.e[0] * v.e[2], u.e[0] * v.e[1] - u.e[1] * v.e[0]);
+}
+inline double len2(const V3& v) { return v.e[0] * v.e[0] + v.e[1] * v.e[1] + v.e[2] * v.e[2]; }
+inline double len(const V3& v) { return std::sqrt(len2(v)); }
+inline V3 unit(const V3& v) {
+    double l = len(v);
+    if (l < 1e-8) return V3(0, 0, 0);
+    return v / l;
+}
+inline bool near_zero(const V3& v) { return std::fabs(v.e[0]) < 1e-8 && std::fabs(v.e[1]) < 1e-8 && std::fabs(v.e[2]) < 1e-8; }
+inline V3 reflect(const V3& v, const V3& n) { return v - 2 * dot(v, n) * n; }
+inline V3 refract(const V3& uv, const V3& n, double eta) {
+    double ct = std::fmin(dot(-uv, n), 1.0);
+    V3 perp = eta * (uv + ct * n);
+    V3 par = -std::sqrt(std::fabs(1.0 - len2(perp))) * n;
+    return perp + par;
+}
+inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (hi < v ? hi : v); }  // std::clamp
+inline double smoothstep(double e0, double e1, double x) {
+    x = clampd((x - e0) / (e1 - e0), 0.0, 1.0);
+    return x * x * (3 - 2 * x);
+}
+
+struct Ray { V3 o, d; };
+inline V3 at(const Ray& r, double t) { return r.o + t * r.d; }
+
+struct Rec {
+    V3 p, n, tan, bit;
+    uint32_t mat = 0xFFFFFFFFu;
+    bool front = false;
+    double t = 0, u = 0, v = 0;
+};
+inline void set_face(Rec& rec, const Ray& r, const V3& outward) {
+    rec.front = dot(r.d, outward) < 0;
+    rec.n = rec.front ? outward : -outward;
+}
+
+struct Box { double lo[3], hi[3]; };
+
+struct Rng {
+    uint64_t key = 0, k = 0, draws = 0;
+    uint32_t bounce = 0;
+    double next() { draws++; return zr_bits_to_unit(zr_stream_bits(key, k++)); }
+    double range(double a, double b) { return a + (b - a) * next(); }
+    double medium(uint32_t id) const { return zr_bits_to_unit(zr_medium_bits(key, bounce, id)); }
+};
+
+inline V3 random_unit_vector(Rng& g) {  // vec3.hpp:184-191, x then y then z
+    for (;;) {
+        double x = g.range(-1, 1);
+        double y = g.range(-1, 1);
+        double z = g.range(-1, 1);
+        V3 p(x, y, z);
+        double l2 = len2(p);
+        if (1e-160 < l2 && l2 <= 1) return p / std::sqrt(l2);
+    }
+}
+
+struct Counters { uint64_t segments = 0, nodes = 0, sph = 0, tri = 0, cube = 0, med = 0, hits = 0, draws = 0, primary = 0; };
+
+struct ONode { Box box; int left, right; uint32_t first, count; };  // private BVH (leaf: count > 0)
+
+struct Scene {
+    zr_scene_desc d{};
+    std::vector<zr_object> objects;      // world list (explicit or implicit)
+    std::vector<uint32_t> medium_of_obj; // unused helper
+    std::vector<Box> obj_box;
+    std::vector<ONode> nodes;
+    std::vector<uint32_t> order;         // object indices in leaf order
+    bool use_bvh = false;
+
+    // ---- textures (texture.hpp) ----
+    V3 tex_value(uint32_t id, double u, double v, const V3& p) const {
+        for (int guard = 0; guard < 64; guard++) {
+            const zr_texture& t = d.textures[id];
+            if (t.kind == ZR_TEX_SOLID) return V3(t.color[0], t.color[1], t.color[2]);
+            if (t.kind == ZR_TEX_CHECKER) {
+                int xi = static_cast<int>(std::floor(t.inv_scale * p.x()));
+                int yi = static_cast<int>(std::floor(t.inv_scale * p.y()));
+                int zi = static_cast<int>(std::floor(t.inv_scale * p.z()));
+                bool even = (xi + yi + zi) % 2 == 0;
+                id = even ? t.even : t.odd;
+                continue;
+            }
+            if (t.width == 0 || t.height == 0) return V3(0.0, 1.0, 1.0);  // texture.hpp:52-54
+            int width = (int)t.width, height = (int)t.height;
+            u = u - std::floor(u);
+            int i = static_cast<int>(u * width);
+            int j = static_cast<int>(v * height);
+            i = std::clamp(i, 0, width - 1);
+            j = std::clamp(j, 0, height - 1);
+            const unsigned char* base = (const unsigned char*)d.texels + t.texel_offset;
+            if (t.kind == ZR_TEX_IMAGE_F32) {
+                const float* px = (const float*)base + (size_t)j * width * 3 + (size_t)i * 3;
+                return V3(px[0], px[1], px[2]);
+            }
+            const double scale = 1.0 / 255.0;
+            const unsigned char* px = base + (size_t)j * width * 3 + (size_t)i * 3;
+            return V3(scale * px[0], scale * px[1], scale * px[2]);
+        }
+        return V3(0, 0, 0);
+    }
+
+    V3 bumped_normal(const Rec& rec, uint32_t bump, double strength) const {  // material.hpp:35-54
+        if (bump == ZR_NO_TEXTURE) return rec.n;
+        double du = 1.0 / 1024.0, dv = 1.0 / 1024.0;
+        double hc = tex_value(bump, rec.u, rec.v, rec.p).x();
+        double hu = tex_value(bump, rec.u + du, rec.v, rec.p).x();
+        double hv = tex_value(bump, rec.u, rec.v + dv, rec.p).x();
+        double fu = (hu - hc) * strength;
+        double fv = (hv - hc) * strength;
+        V3 b = rec.n - (fu * rec.tan) - (fv * rec.bit);
+        return unit(b);
+    }
+
+    V3 emitted(const Rec& rec) const {
+        const zr_material& m = d.materials[rec.mat];
+        if (m.kind == ZR_MAT_LIGHT) return tex_value(m.tex, rec.u, rec.v, rec.p);
+        return V3(0, 0, 0);
+    }
+
+    bool scatter(const Ray& rin, const Rec& rec, V3& att, Ray& out, Rng& g) const {
+        const zr_material& m = d.materials[rec.mat];
+        switch (m.kind) {
+            case ZR_MAT_LAMBERTIAN: {  // material.hpp:74-96
+                V3 wn = rec.n;
+                if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(rec, m.bump_tex, m.bump_strength);
+                V3 dir = wn + random_unit_vector(g);
+                if (near_zero(dir)) dir = wn;
+                V3 org = rec.p + (rec.n * kRayEps);
+                out = Ray{org, dir};
+                att = tex_value(m.tex, rec.u, rec.v, rec.p);
+                return true;
+            }
+            case ZR_MAT_METAL: {  // material.hpp:129-151
+                V3 wn = rec.n;
+                if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(rec, m.bump_tex, m.bump_strength);
+                V3 v = unit(rin.d);
+                V3 refl = reflect(v, wn);
+                V3 dir = unit(refl + (m.param * random_unit_vector(g)));
+                V3 org = rec.p + (kRayEps * rec.n);
+                out = Ray{org, dir};
+                att = tex_value(m.tex, rec.u, rec.v, rec.p);
+                return dot(out.d, rec.n) > 0;
+            }
+            case ZR_MAT_DIELECTRIC: {  // material.hpp:192-224, 237-241
+                att = V3(m.tint[0], m.tint[1], m.tint[2]);
+                V3 wn = rec.n;
+                if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(rec, m.bump_tex, m.bump_strength);
+                double ri = rec.front ? (1.0 / m.param) : m.param;
+                V3 ud = unit(rin.d);
+                double ct = std::fmin(dot(-ud, wn), 1.0);
+                double st = std::sqrt(1.0 - ct * ct);
+                bool cannot = ri * st > 1.0;
+                V3 dir;
+                bool refl = cannot;
+                if (!refl) {
+                    double r0 = (1 - ri) / (1 + ri);
+                    r0 = r0 * r0;
+                    double rf = r0 + (1 - r0) * std::pow((1 - ct), 5);
+                    refl = rf > g.next();
+                }
+                if (refl) dir = reflect(ud, wn); else dir = refract(ud, wn, ri);
+                V3 off = (dot(dir, rec.n) > 0) ? (kRayEps * rec.n) : (-kRayEps * rec.n);
+                out = Ray{rec.p + off, dir};
+                return true;
+            }
+            case ZR_MAT_ISOTROPIC: {  // constant_medium.hpp:14-18
+                out = Ray{rec.p, random_unit_vector(g)};
+                att = tex_value(m.tex, rec.u, rec.v, rec.p);
+                return true;
+            }
+            default:  // ZR_MAT_LIGHT, material.hpp:255-259
+                return false;
+        }
+    }
+
+    // ---- primitives ----
+    bool hit_sphere(uint32_t idx, const Ray& r, double tmin, double tmax, Rec& rec, Counters* c) const {
+        if (c) c->sph++;
+        const double* s = d.spheres + (size_t)idx * 4;
+        V3 center(s[0], s[1], s[2]);
+        double radius = std::fmax(0, s[3]);
+        V3 oc = center - r.o;
+        double a = len2(r.d);
+        double h = dot(r.d, oc);
+        double cc = len2(oc) - radius * radius;
+        double disc = h * h - a * cc;
+        if (disc < 0) return false;
+        double sq = std::sqrt(disc);
+        double root = (h - sq) / a;
+        if (!(tmin < root && tmax > root)) {
+            root = (h + sq) / a;
+            if (!(tmin < root && tmax > root)) return false;
+        }
+        rec.t = root;
+        rec.p = at(r, rec.t);
+        V3 outward = (rec.p - center) / radius;
+        set_face(rec, r, outward);
+        double theta = std::acos(-outward.y());
+        double phi = std::atan2(-outward.z(), outward.x()) + kPi;
+        rec.u = phi / (2 * kPi);
+        rec.v = theta / kPi;
+        rec.tan = cross(V3(0, 1, 0), rec.n);
+        if (len2(rec.tan) < 0.001) rec.tan = cross(V3(0, 0, 1), rec.n);
+        rec.tan = unit(rec.tan);
+        rec.bit = cross(rec.n, rec.tan);
+        rec.mat = d.sphere_mat[idx];
+        return true;
+    }
+
+    bool hit_triangle(uint32_t idx, const Ray& r, double tmin, double tmax, Rec& rec, Counters* c) const {
+        if (c) c->tri++;
+        const double* vv = d.tri_v + (size_t)idx * 9;
+        const double* nn = d.tri_n + (size_t)idx * 9;
+        V3 v0(vv[0], vv[1], vv[2]), v1(vv[3], vv[4], vv[5]), v2(vv[6], vv[7], vv[8]);
+        V3 e1 = v1 - v0, e2 = v2 - v0;
+        V3 normal = cross(e1, e2);
+        double nl = len(normal);
+        if (nl < 1e-8) return false;
+        V3 un = normal / nl;
+        double nd = dot(un, r.d);
+        if (std::fabs(nd) < 1e-8) return false;
+        double D = dot(un, v0);
+        double t = (D - dot(un, r.o)) / nd;
+        if (!(tmin <= t && t <= tmax)) return false;
+        V3 p = at(r, t);
+        V3 C0 = cross(v1 - v0, p - v0);
+        V3 C1 = cross(v2 - v1, p - v1);
+        V3 C2 = cross(v0 - v2, p - v2);
+        if (dot(normal, C0) < 0 || dot(normal, C1) < 0 || dot(normal, C2) < 0) return false;
+        double area2 = dot(normal, normal);
+        double u = dot(normal, C2) / area2;
+        double v = dot(normal, C0) / area2;
+        double w = 1.0 - u - v;
+        V3 n0(nn[0], nn[1], nn[2]), n1(nn[3], nn[4], nn[5]), n2(nn[6], nn[7], nn[8]);
+        V3 smooth = unit(w * n0 + u * n1 + v * n2);
+        rec.t = t;
+        rec.p = p;
+        rec.mat = d.tri_mat[idx];
+        set_face(rec, r, smooth);
+        // triangle::hit leaves u, v, tangent, bitangent untouched (triangle.hpp:72-79): in the reference they
+        // hold whatever an earlier candidate of the same traversal wrote.  Contract here: the fresh
+        // hit_record values (0) — see DESIGN.md "quirks".
+        rec.u = 0; rec.v = 0; rec.tan = V3(); rec.bit = V3();
+        return true;
+    }
+
+    bool hit_cube(uint32_t idx, const Ray& r, double tmin, double tmax, Rec& rec, Counters* c) const {
+        if (c) c->cube++;
+        const double* q = d.cubes + (size_t)idx * 12;
+        V3 he(q[0], q[1], q[2]), center(q[3], q[4], q[5]);
+        for (int i = 0; i < 3; ++i) {
+            double mn = -he[i], mx = he[i];
+            double inv = 1.0 / r.d[i];
+            double t0 = (mn - r.o[i]) * inv;  // cube.hpp:57-58 uses r.origin(), not the centred origin
+            double t1 = (mx - r.o[i]) * inv;
+            if (inv < 0.0) std::swap(t0, t1);
+            tmin = std::fmax(t0, tmin);
+            tmax = std::fmin(t1, tmax);
+            if (tmax < tmin) return false;
+        }
+        rec.t = tmin;
+        rec.p = at(r, rec.t);
+        V3 p = rec.p - center;
+        const double EPS = 1e-3;
+        if (std::fabs(p.x() + he.x()) < EPS) {
+            rec.n = V3(-1, 0, 0); rec.u = (p.z() + he.z()) / (2 * he.z()); rec.v = (p.y() + he.y()) / (2 * he.y()); rec.tan = V3(0, 0, 1);
+        } else if (std::fabs(p.x() - he.x()) < EPS) {
+            rec.n = V3(1, 0, 0); rec.u = (p.z() + he.z()) / (2 * he.z()); rec.v = (p.y() + he.y()) / (2 * he.y()); rec.tan = V3(0, 0, -1);
+        } else if (std::fabs(p.y() + he.y()) < EPS) {
+            rec.n = V3(0, -1, 0); rec.u = (p.x() + he.x()) / (2 * he.x()); rec.v = (p.z() + he.z()) / (2 * he.z()); rec.tan = V3(1, 0, 0);
+        } else if (std::fabs(p.y() - he.y()) < EPS) {
+            rec.n = V3(0, 1, 0); rec.u = (p.x() + he.x()) / (2 * he.x()); rec.v = (p.z() + he.z()) / (2 * he.z()); rec.tan = V3(-1, 0, 0);
+        } else if (std::fabs(p.z() + he.z()) < EPS) {
+            rec.n = V3(0, 0, -1); rec.u = (he.x() - p.x()) / (2 * he.x()); rec.v = (p.y() + he.y()) / (2 * he.y()); rec.tan = V3(-1, 0, 0);
+        } else {
+            rec.n = V3(0, 0, 1); rec.u = (p.x() + he.x()) / (2 * he.x()); rec.v = (p.y() + he.y()) / (2 * he.y()); rec.tan = V3(1, 0, 0);
+        }
+        rec.bit = cross(rec.n, rec.tan);
+        rec.mat = d.cube_mat[idx];
+        set_face(rec, r, rec.n);
+        return true;
+    }
+
+    bool hit_medium(uint32_t idx, const Ray& r, double tmin, double tmax, Rec& rec, const Rng& g, Counters* c) const {
+        if (c) c->med++;
+        const zr_medium& m = d.media[idx];
+        Rec r1, r2;
+        if (!hit_chain(m.boundary_type, m.boundary_index, m.chain_first, m.chain_count, r, -kInf, kInf, r1, g, nullptr)) return false;
+        if (!hit_chain(m.boundary_type, m.boundary_index, m.chain_first, m.chain_count, r, r1.t + 0.0001, kInf, r2, g, nullptr)) return false;
+        if (r1.t < tmin) r1.t = tmin;
+        if (r2.t > tmax) r2.t = tmax;
+        if (r1.t >= r2.t) return false;
+        if (r1.t < 0) r1.t = 0;
+        double rl = len(r.d);
+        double inside = (r2.t - r1.t) * rl;
+        double hd = m.neg_inv_density * std::log(g.medium(idx));
+        if (hd > inside) return false;
+        rec.t = r1.t + hd / rl;
+        rec.p = at(r, rec.t);
+        rec.n = V3(1, 0, 0);
+        rec.front = true;
+        rec.mat = m.mat;
+        // u, v, tangent, bitangent untouched by constant_medium::hit: fresh-record values
+        rec.u = 0; rec.v = 0; rec.tan = V3(); rec.bit = V3();
+        return true;
+    }
+
+    bool hit_prim(uint32_t type, uint32_t idx, const Ray& r, double tmin, double tmax, Rec& rec, const Rng& g, Counters* c) const {
+        switch (type) {
+            case ZR_PRIM_SPHERE: return hit_sphere(idx, r, tmin, tmax, rec, c);
+            case ZR_PRIM_TRIANGLE: return hit_triangle(idx, r, tmin, tmax, rec, c);
+            case ZR_PRIM_CUBE: return hit_cube(idx, r, tmin, tmax, rec, c);
+            default: return hit_medium(idx, r, tmin, tmax, rec, g, c);
+        }
+    }
+
+    // wrappers, outermost first
+    bool hit_chain(uint32_t type, uint32_t idx, uint32_t cf, uint32_t cn, const Ray& r, double tmin, double tmax, Rec& rec,
+                   const Rng& g, Counters* c) const {
+        if (cn == 0) return hit_prim(type, idx, r, tmin, tmax, rec, g, c);
+        const zr_xform_op& op = d.ops[cf];
+        switch (op.kind) {
+            case ZR_OP_TRANSLATE: {  // translate.hpp:15-32
+                V3 off(op.a[0], op.a[1], op.a[2]);
+                Ray m{r.o - off, r.d};
+                if (!hit_chain(type, idx, cf + 1, cn - 1, m, tmin, tmax, rec, g, c)) return false;
+                rec.p = rec.p + off;
+                set_face(rec, r, rec.n);
+                return true;
+            }
+            case ZR_OP_ROTATE_Y: {  // rotate_y.hpp:41-73
+                double s = op.a[0], co = op.a[1];
+                Ray m = r;
+                m.o[0] = co * r.o[0] + s * r.o[2];
+                m.o[2] = -s * r.o[0] + co * r.o[2];
+                m.d[0] = co * r.d[0] + s * r.d[2];
+                m.d[2] = -s * r.d[0] + co * r.d[2];
+                if (!hit_chain(type, idx, cf + 1, cn - 1, m, tmin, tmax, rec, g, c)) return false;
+                V3 p = rec.p, n = rec.n;
+                p[0] = co * rec.p[0] - s * rec.p[2];
+                p[2] = s * rec.p[0] + co * rec.p[2];
+                n[0] = co * rec.n[0] - s * rec.n[2];
+                n[2] = s * rec.n[0] + co * rec.n[2];
+                rec.p = p;
+                set_face(rec, r, n);
+                return true;
+            }
+            case ZR_OP_ROTATE_X: {  // rotate_x.hpp:42-70 (front_face is NOT refreshed)
+                double s = op.a[0], co = op.a[1];
+                Ray m = r;
+                m.o[1] = co * r.o[1] + s * r.o[2];
+                m.o[2] = -s * r.o[1] + co * r.o[2];
+                m.d[1] = co * r.d[1] + s * r.d[2];
+                m.d[2] = -s * r.d[1] + co * r.d[2];
+                if (!hit_chain(type, idx, cf + 1, cn - 1, m, tmin, tmax, rec, g, c)) return false;
+                V3 p = rec.p, n = rec.n;
+                p[1] = co * rec.p[1] - s * rec.p[2];
+                p[2] = s * rec.p[1] + co * rec.p[2];
+                n[1] = co * rec.n[1] - s * rec.n[2];
+                n[2] = s * rec.n[1] + co * rec.n[2];
+                rec.p = p; rec.n = n;
+                return true;
+            }
+            case ZR_OP_ROTATE_Z: {  // rotate_z.hpp:40-66
+                double s = op.a[0], co = op.a[1];
+                Ray m = r;
+                m.o[0] = co * r.o[0] + s * r.o[1];
+                m.o[1] = -s * r.o[0] + co * r.o[1];
+                m.d[0] = co * r.d[0] + s * r.d[1];
+                m.d[1] = -s * r.d[0] + co * r.d[1];
+                if (!hit_chain(type, idx, cf + 1, cn - 1, m, tmin, tmax, rec, g, c)) return false;
+                V3 p = rec.p, n = rec.n;
+                p[0] = co * rec.p[0] - s * rec.p[1];
+                p[1] = s * rec.p[0] + co * rec.p[1];
+                n[0] = co * rec.n[0] - s * rec.n[1];
+                n[1] = s * rec.n[0] + co * rec.n[1];
+                rec.p = p; rec.n = n;
+                return true;
+            }
+            case ZR_OP_SCALE: {  // scale.hpp:20-36
+                V3 sc(op.a[0], op.a[1], op.a[2]);
+                Ray m{V3(r.o.x() / sc.x(), r.o.y() / sc.y(), r.o.z() / sc.z()), V3(r.d.x() / sc.x(), r.d.y() / sc.y(), r.d.z() / sc.z())};
+                if (!hit_chain(type, idx, cf + 1, cn - 1, m, tmin, tmax, rec, g, c)) return false;
+                rec.p = V3(rec.p.x() * sc.x(), rec.p.y() * sc.y(), rec.p.z() * sc.z());
+                V3 ln(rec.n.x() / sc.x(), rec.n.y() / sc.y(), rec.n.z() / sc.z());
+                rec.n = unit(ln);
+                return true;
+            }
+            default: {  // ZR_OP_MATERIAL, material_instance.hpp:12-28
+                if (!hit_chain(type, idx, cf + 1, cn - 1, r, tmin, tmax, rec, g, c)) return false;
+                rec.mat = op.mat;
+                return true;
+            }
+        }
+    }
+
+    bool hit_object(uint32_t oi, const Ray& r, double tmin, double tmax, Rec& rec, const Rng& g, Counters* c) const {
+        const zr_object& o = objects[oi];
+        return hit_chain(o.type, o.index, o.chain_first, o.chain_count, r, tmin, tmax, rec, g, c);
+    }
+
+    // ---- bounding boxes (conservative; follow the reference's constructors) ----
+    static void box_union(Box& a, const Box& b) {
+        for (int k = 0; k < 3; k++) { a.lo[k] = std::fmin(a.lo[k], b.lo[k]); a.hi[k] = std::fmax(a.hi[k], b.hi[k]); }
+    }
+    Box prim_box(uint32_t type, uint32_t idx) const {
+        Box b;
+        if (type == ZR_PRIM_SPHERE) {
+            const double* s = d.spheres + (size_t)idx * 4;
+            for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(s[k] - s[3], s[k] + s[3]); b.hi[k] = std::fmax(s[k] - s[3], s[k] + s[3]); }
+        } else if (type == ZR_PRIM_TRIANGLE) {
+            const double* v = d.tri_v + (size_t)idx * 9;
+            for (int k = 0; k < 3; k++) {
+                b.lo[k] = std::fmin(v[k], std::fmin(v[3 + k], v[6 + k]));
+                b.hi[k] = std::fmax(v[k], std::fmax(v[3 + k], v[6 + k]));
+                if (b.hi[k] - b.lo[k] < 0.0001) { b.lo[k] -= 0.0001; b.hi[k] += 0.0001; }
+            }
+        } else if (type == ZR_PRIM_CUBE) {
+            const double* q = d.cubes + (size_t)idx * 12;
+            for (int k = 0; k < 3; k++) { b.lo[k] = q[6 + k] - 0.00005; b.hi[k] = q[9 + k] + 0.00005; }
+        } else {
+            const zr_medium& m = d.media[idx];
+            b = chain_box(m.boundary_type, m.boundary_index, m.chain_first, m.chain_count);
+        }
+        return b;
+    }
+    Box chain_box(uint32_t type, uint32_t idx, uint32_t cf, uint32_t cn) const {
+        if (cn == 0) return prim_box(type, idx);
+        Box in = chain_box(type, idx, cf + 1, cn - 1);
+        const zr_xform_op& op = d.ops[cf];
+        Box b;
+        if (op.kind == ZR_OP_TRANSLATE) {
+            for (int k = 0; k < 3; k++) { b.lo[k] = in.lo[k] + op.a[k]; b.hi[k] = in.hi[k] + op.a[k]; }
+            return b;
+        }
+        if (op.kind == ZR_OP_SCALE) {
+            for (int k = 0; k < 3; k++) { double a0 = in.lo[k] * op.a[k], a1 = in.hi[k] * op.a[k]; b.lo[k] = std::fmin(a0, a1); b.hi[k] = std::fmax(a0, a1); }
+            return b;
+        }
+        if (op.kind == ZR_OP_MATERIAL) return in;
+        for (int k = 0; k < 3; k++) { b.lo[k] = kInf; b.hi[k] = -kInf; }
+        double s = op.a[0], co = op.a[1];
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+            double x = i ? in.hi[0] : in.lo[0], y = j ? in.hi[1] : in.lo[1], z = k ? in.hi[2] : in.lo[2];
+            double t[3] = {x, y, z};
+            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x + s * z; t[2] = -s * x + co * z; }
+            else if (op.kind == ZR_OP_ROTATE_X) { t[1] = co * y - s * z; t[2] = s * y + co * z; }
+            else { t[0] = co * x - s * y; t[1] = s * x + co * y; }
+            for (int q = 0; q < 3; q++) { b.lo[q] = std::fmin(b.lo[q], t[q]); b.hi[q] = std::fmax(b.hi[q], t[q]); }
+        }
+        return b;
+    }
+
+    // ---- private BVH ----
+    int build_node(uint32_t first, uint32_t count) {
+        ONode n;
+        n.box = obj_box[order[first]];
+        for (uint32_t k = 1; k < count; k++) box_union(n.box, obj_box[order[first + k]]);
+        n.left = n.right = -1; n.first = first; n.count = count;
+        int id = (int)nodes.size();
+        nodes.push_back(n);
+        if (count <= 2) return id;
+        double clo[3] = {kInf, kInf, kInf}, chi[3] = {-kInf, -kInf, -kInf};
+        for (uint32_t k = 0; k < count; k++) {
+            const Box& b = obj_box[order[first + k]];
+            for (int a = 0; a < 3; a++) { double c = 0.5 * (b.lo[a] + b.hi[a]); clo[a] = std::fmin(clo[a], c); chi[a] = std::fmax(chi[a], c); }
+        }
+        int ax = 0; if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1; if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        uint32_t mid = first + count / 2;
+        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
+            return obj_box[a].lo[ax] + obj_box[a].hi[ax] < obj_box[b].lo[ax] + obj_box[b].hi[ax];
+        });
+        int l = build_node(first, mid - first);
+        int r = build_node(mid, first + count - mid);
+        nodes[id].left = l; nodes[id].right = r; nodes[id].count = 0;
+        return id;
+    }
+
+    static bool box_hit(const Box& b, const Ray& r, double tmin, double tmax) {  // aabb.hpp:44-66
+        for (int a = 0; a < 3; a++) {
+            double inv = 1.0 / r.d[a];
+            double t0 = (b.lo[a] - r.o[a]) * inv, t1 = (b.hi[a] - r.o[a]) * inv;
+            if (inv < 0.0) std::swap(t0, t1);
+            if (t0 > tmin) tmin = t0;
+            if (t1 < tmax) tmax = t1;
+            if (tmax < tmin) return false;  // conservative (<, not <=): only ever tests MORE objects than the reference
+        }
+        return true;
+    }
+
+    void prepare() {
+        if (d.n_objects) {
+            objects.assign(d.objects, d.objects + d.n_objects);
+        } else {
+            std::vector<char> sb(d.n_spheres, 0), cb(d.n_cubes, 0);
+            for (uint64_t k = 0; k < d.n_media; k++) {
+                if (d.media[k].boundary_type == ZR_PRIM_SPHERE) sb[d.media[k].boundary_index] = 1; else cb[d.media[k].boundary_index] = 1;
+            }
+            for (uint32_t k = 0; k < d.n_spheres; k++) if (!sb[k]) objects.push_back({ZR_PRIM_SPHERE, k, 0, 0});
+            for (uint32_t k = 0; k < d.n_tris; k++) objects.push_back({ZR_PRIM_TRIANGLE, k, 0, 0});
+            for (uint32_t k = 0; k < d.n_cubes; k++) if (!cb[k]) objects.push_back({ZR_PRIM_CUBE, k, 0, 0});
+            for (uint32_t k = 0; k < d.n_media; k++) objects.push_back({ZR_PRIM_MEDIUM, k, 0, 0});
+        }
+        use_bvh = objects.size() > 16;
+        if (use_bvh) {
+            obj_box.resize(objects.size());
+            order.resize(objects.size());
+            for (size_t k = 0; k < objects.size(); k++) {
+                const zr_object& o = objects[k];
+                obj_box[k] = chain_box(o.type, o.index, o.chain_first, o.chain_count);
+                // pad: guards the conservative test against 1-ulp effects on axis-aligned geometry
+                for (int a = 0; a < 3; a++) {
+                    double pad = 1e-9 * (std::fabs(obj_box[k].lo[a]) + std::fabs(obj_box[k].hi[a]) + 1.0);
+                    obj_box[k].lo[a] -= pad; obj_box[k].hi[a] += pad;
+                }
+                order[k] = (uint32_t)k;
+            }
+            nodes.reserve(objects.size());
+            build_node(0, (uint32_t)objects.size());
+        }
+    }
+
+    bool world_hit(const Ray& r, double tmin, double tmax, Rec& rec, const Rng& g, Counters* c) const {
+        if (c) c->segments++;
+        bool any = false;
+        if (!use_bvh) {
+            for (uint32_t k = 0; k < objects.size(); k++) {
+                Rec tmp;
+                if (hit_object(k, r, tmin, tmax, tmp, g, c)) { any = true; tmax = tmp.t; rec = tmp; }
+            }
+        } else {
+            int stack[128]; int sp = 0; stack[sp++] = 0;
+            while (sp) {
+                const ONode& n = nodes[stack[--sp]];
+                if (c) c->nodes++;
+                if (!box_hit(n.box, r, tmin, tmax)) continue;
+                if (n.count) {
+                    for (uint32_t k = 0; k < n.count; k++) {
+                        Rec tmp;
+                        if (hit_object(order[n.first + k], r, tmin, tmax, tmp, g, c)) { any = true; tmax = tmp.t; rec = tmp; }
+                    }
+                } else {
+                    stack[sp++] = n.right; stack[sp++] = n.left;
+                }
+            }
+        }
+        if (any && c) c->hits++;
+        return any;
+    }
+};
+
+struct Cam {
+    zr_camera c;
+    V3 center, pixel00, du, dv, u, v, w, disk_u, disk_v;
+    void initialize() {  // camera.hpp:358-399
+        if (c.image_width < 1) c.image_width = 1;
+        if (c.image_height < 1) c.image_height = 1;
+        double aspect = double(c.image_width) / c.image_height;
+        center = V3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
+        V3 lookat(c.lookat[0], c.lookat[1], c.lookat[2]), vup(c.vup[0], c.vup[1], c.vup[2]);
+        double theta = c.vfov * kPi / 180.0;
+        double h = std::tan(theta / 2);
+        double vh = 2 * h * c.focus_dist;
+        double vw = vh * aspect;
+        w = unit(center - lookat);
+        u = unit(cross(vup, w));
+        v = cross(w, u);
+        V3 vu = vw * u;
+        V3 vv = vh * -v;
+        du = vu / c.image_width;
+        dv = vv / c.image_height;
+        V3 ul = center - (c.focus_dist * w) - vu / 2 - vv / 2;
+        pixel00 = ul + 0.5 * (du + dv);
+        double rad = c.focus_dist * std::tan((c.defocus_angle / 2) * kPi / 180.0);
+        disk_u = u * rad;
+        disk_v = v * rad;
+    }
+    Ray get_ray(int i, int j, Rng& g) const {  // camera.hpp:784-794, 817-825
+        double ox = g.next() - 0.5;
+        double oy = g.next() - 0.5;
+        V3 ps = pixel00 + ((i + ox) * du) + ((j + oy) * dv);
+        V3 org = center;
+        if (!(c.defocus_angle <= 0)) {
+            V3 p;
+            for (;;) {  // random_in_unit_disk, vec3.hpp:174-181
+                double x = g.range(-1, 1);
+                double y = g.range(-1, 1);
+                p = V3(x, y, 0);
+                if (len2(p) < 1) break;
+            }
+            org = center + (p[0] * disk_u) + (p[1] * disk_v);
+        }
+        return Ray{org, ps - org};
+    }
+};
+
+V3 background(const Scene& sc, const zr_env& env, const Ray& r) {  // camera.hpp:828-925
+    V3 ud = unit(r.d);
+    V3 bg(env.background_color[0], env.background_color[1], env.background_color[2]);
+    if (env.mode == ZR_ENV_SOLID_COLOR) return bg * env.intensity;
+    if (env.mode == ZR_ENV_HDR_MAP) {
+        if (env.hdr_texture == ZR_NO_TEXTURE) return V3(0, 0, 0);
+        V3 d = ud;
+        double cy = std::cos(env.hdri_rotation), sy = std::sin(env.hdri_rotation);
+        double x1 = cy * d.x() + sy * d.z();
+        double z1 = -sy * d.x() + cy * d.z();
+        d = V3(x1, d.y(), z1);
+        double cp = std::cos(env.hdri_tilt), sp = std::sin(env.hdri_tilt);
+        double y2 = cp * d.y() - sp * d.z();
+        double z2 = sp * d.y() + cp * d.z();
+        d = V3(d.x(), y2, z2);
+        double cr = std::cos(env.hdri_roll), sr = std::sin(env.hdri_roll);
+        double x3 = cr * d.x() - sr * d.y();
+        double y3 = sr * d.x() + cr * d.y();
+        d = V3(x3, y3, d.z());
+        double phi = std::atan2(d.z(), d.x()) + kPi;
+        double theta = std::acos(clampd(d.y(), -1.0, 1.0));
+        return sc.tex_value(env.hdr_texture, phi / (2 * kPi), theta / kPi, V3(0, 0, 0)) * env.intensity;
+    }
+    V3 sun = unit(V3(env.sun_direction[0], env.sun_direction[1], env.sun_direction[2]));
+    double sh = sun.y();
+    double ah = sh - 0.05;
+    double sky_exposure = clampd(ah * 8.0 + 1.4, 0.0, 1.0);
+    double day = clampd(ah * 10.0 + 1.1, 0.0, 1.0);
+    double sunset_i = clampd(1.0 - std::fabs(ah + 0.05) * 30.0, 0.0, 1.0);
+    double sunset = (ah > -0.1) ? sunset_i : 0.0;
+    if (sh < 0) sunset *= (sh * 10.0 + 1.0);
+    sunset = clampd(sunset, 0.0, 1.0);
+    V3 zen = V3(0.01, 0.03, 0.1) * (1.0 - day) + V3(0.2, 0.5, 1.0) * day;
+    V3 hor = V3(0.05, 0.02, 0.01) * (1.0 - day) + V3(0.6, 0.8, 1.0) * day;
+    hor = hor * (1.0 - sunset) + V3(1.0, 0.35, 0.1) * sunset;
+    double a = ud.y();
+    V3 sky;
+    if (a > 0.0) sky = (1.0 - a) * hor + a * zen; else sky = hor * 0.1;
+    V3 fin = sky * (env.intensity * 1.5) * sky_exposure;
+    double focus = dot(ud, sun);
+    double thr = 1.0 - (env.sun_size * 0.001);
+    if (focus > thr && ah > -0.1) {
+        V3 scol = V3(env.sun_color[0], env.sun_color[1], env.sun_color[2]) * (1.0 - sunset) + V3(1.0, 0.3, 0.1) * sunset;
+        double vis = clampd(sh * 5.0 + 1.0, 0.0, 1.0);
+        double alpha = smoothstep(thr, thr + 0.0002, focus);
+        fin = fin + scol * env.sun_intensity * vis * alpha;
+    }
+    return fin;
+}
+
+V3 ray_color(const Scene& sc, const zr_env& env, const Ray& r0, int depth, Rng& g, Counters* c) {  // camera.hpp:928-986
+    V3 L(0, 0, 0), beta(1, 1, 1);
+    Ray cur = r0;
+    for (int i = 0; i < depth; i++) {
+        Rec rec;
+        bool h = sc.world_hit(cur, 0.001, kInf, rec, g, c);
+        g.bounce++;
+        if (!h) return L + beta * background(sc, env, cur);
+        V3 em = sc.emitted(rec);
+        L = L + beta * em;
+        Ray out; V3 att;
+        if (sc.scatter(cur, rec, att, out, g)) {
+            beta = beta * att;
+            cur = out;
+            if (i > 10 && len(beta) < 0.0001) break;
+        } else {
+            break;
+        }
+        if (i > 10) {
+            double p = std::max({beta.x(), beta.y(), beta.z()});
+            p = clampd(p, 0.05, 0.95);
+            if (g.next() > p) break;
+            beta = beta * (1 / p);  // operator/= is *= 1/t (vec3.hpp:77-79)
+        }
+    }
+    return L;
+}
+
+V3 sample_radiance(const Scene& sc, const Cam& cam, const zr_env& env, int i, int j, Rng& g, Counters* c) {
+    Ray r = cam.get_ray(i, j, g);
+    Rec rec;
+    bool h = sc.world_hit(r, 0.001, kInf, rec, g, c);
+    g.bounce++;
+    if (!h) return background(sc, env, r);
+    // ray_color_from_hit, camera.hpp:989-1004
+    V3 L = sc.emitted(rec);
+    V3 beta(1, 1, 1);
+    Ray out; V3 att;
+    if (sc.scatter(r, rec, att, out, g)) {
+        beta = beta * att;
+        return L + beta * ray_color(sc, env, out, cam.c.max_depth - 1, g, c);
+    }
+    return L;
+}
+
+void to_hit(const Rec& rec, bool h, zr_hit& o) {
+    std::memset(&o, 0, sizeof(o));
+    o.mat = 0xFFFFFFFFu;
+    if (!h) return;
+    for (int k = 0; k < 3; k++) { o.p[k] = rec.p[k]; o.normal[k] = rec.n[k]; o.tangent[k] = rec.tan[k]; o.bitangent[k] = rec.bit[k]; }
+    o.t = rec.t; o.u = rec.u; o.v = rec.v; o.mat = rec.mat; o.front_face = rec.front ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* zro_scene_create(const zr_scene_desc* d) {
+    Scene* s = new Scene();
+    s->d = *d;
+    s->prepare();
+    return s;
+}
+void zro_scene_destroy(void* s) { delete (Scene*)s; }
+
+// out_mean: full-frame layout W*H*3 (only region pixels written).  per_sample (optional): region
+// h*w*spp*3.  counts (optional): region h*w*spp*2 = (segments, main-stream draws).
+int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t seed, const zr_region* region, int threads,
+               double* out_mean, double* per_sample, uint32_t* counts, zr_counters* ctr) {
+    const Scene& sc = *(Scene*)scene;
+    Cam cam; cam.c = *cam_in; cam.initialize();
+    const int W = cam.c.image_width, H = cam.c.image_height, spp = cam.c.samples_per_pixel;
+    int x0 = 0, y0 = 0, w = W, h = H, ts = 32, tmod = 1, trem = 0;
+    if (region) {
+        if (region->w > 0 && region->h > 0) { x0 = region->x0; y0 = region->y0; w = region->w; h = region->h; }
+        if (region->tile_size > 0) ts = region->tile_size;
+        if (region->tile_mod > 1) { tmod = region->tile_mod; trem = region->tile_rem; }
+    }
+    if (x0 < 0 || y0 < 0 || x0 + w > W || y0 + h > H) return ZR_E_INVALID;
+    const int tiles_x = (W + ts - 1) / ts;
+    std::atomic<int> next_row{0};
+    std::vector<Counters> tc((size_t)std::max(1, threads));
+    auto worker = [&](int tid) {
+        Counters& c = tc[tid];
+        for (;;) {
+            int jj = next_row.fetch_add(1);
+            if (jj >= h) break;
+            int j = y0 + jj;
+            for (int ii = 0; ii < w; ii++) {
+                int i = x0 + ii;
+                if (tmod > 1) { int t = (j / ts) * tiles_x + (i / ts); if (t % tmod != trem) continue; }
+                V3 acc(0, 0, 0);
+                for (int s = 0; s < spp; s++) {
+                    Rng g; g.key = zr_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s);
+                    uint64_t seg0 = c.segments;
+                    V3 col = sample_radiance(sc, cam, *env, i, j, g, &c);
+                    c.primary++; c.draws += g.draws;
+                    acc = acc + col;  // camera.hpp:461 (pixel_color += ...)
+                    if (per_sample) { double* o = per_sample + (((size_t)jj * w + ii) * spp + s) * 3; o[0] = col.x(); o[1] = col.y(); o[2] = col.z(); }
+                    if (counts) { uint32_t* o = counts + (((size_t)jj * w + ii) * spp + s) * 2; o[0] = (uint32_t)(c.segments - seg0); o[1] = (uint32_t)g.draws; }
+                }
+                V3 m = acc * (1.0 / spp);
+                double* o = out_mean + ((size_t)j * W + i) * 3;
+                o[0] = m.x(); o[1] = m.y(); o[2] = m.z();
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    int nt = std::max(1, threads);
+    for (int t = 0; t < nt; t++) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+    if (ctr) {
+        std::memset(ctr, 0, sizeof(*ctr));
+        for (const Counters& c : tc) {
+            ctr->primary_samples += c.primary; ctr->segments += c.segments; ctr->nodes_tested += c.nodes;
+            ctr->spheres_tested += c.sph; ctr->triangles_tested += c.tri; ctr->cubes_tested += c.cube;
+            ctr->media_tested += c.med; ctr->hits += c.hits; ctr->rng_draws += c.draws;
+        }
+    }
+    return ZR_OK;
+}
+
+int zro_trace(void* scene, const double* rays6, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel, uint32_t bounce,
+              zr_hit* out) {
+    const Scene& sc = *(Scene*)scene;
+    for (size_t k = 0; k < n; k++) {
+        const double* q = rays6 + k * 6;
+        Ray r{V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5])};
+        Rng g; g.key = zr_stream_key(seed, pixel, k); g.bounce = bounce;
+        Rec rec;
+        bool h = sc.world_hit(r, tmin, tmax, rec, g, nullptr);
+        to_hit(rec, h, out[k]);
+    }
+    return ZR_OK;
+}
+
+// scatter known answers: one scatter of hit `h` by ray `r` with the main stream at draw 0 of `key`
+int zro_scatter(void* scene, const double* ray6, const zr_hit* h, uint64_t key, double* att3, double* out_ray6) {
+    const Scene& sc = *(Scene*)scene;
+    Ray r{V3(ray6[0], ray6[1], ray6[2]), V3(ray6[3], ray6[4], ray6[5])};
+    Rec rec;
+    for (int k = 0; k < 3; k++) { rec.p[k] = h->p[k]; rec.n[k] = h->normal[k]; rec.tan[k] = h->tangent[k]; rec.bit[k] = h->bitangent[k]; }
+    rec.t = h->t; rec.u = h->u; rec.v = h->v; rec.mat = h->mat; rec.front = h->front_face != 0;
+    Rng g; g.key = key;
+    V3 att; Ray out;
+    bool s = sc.scatter(r, rec, att, out, g);
+    for (int k = 0; k < 3; k++) { att3[k] = att[k]; out_ray6[k] = out.o[k]; out_ray6[3 + k] = out.d[k]; }
+    return s ? 1 : 0;
+}
+
+}  // extern "C"

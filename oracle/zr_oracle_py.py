@@ -1,0 +1,119 @@
+"""zr_oracle_py — TEST INFRASTRUCTURE.  ctypes view of the CPU restatement (oracle/libzr_oracle.so) and of the
+genuine-reference harness binary (oracle/_ref/zenith_ref).
+
+May only be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, and only as the
+checker / reported baseline — never by the product path (raytracer_project_amd/).
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_project_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(_HERE, "libzr_oracle.so")
+REF_BIN = os.path.join(_HERE, "_ref", "zenith_ref")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_LIB):
+        build()
+    lib = C.CDLL(ORACLE_LIB)
+    vp = C.c_void_p
+    lib.zro_scene_create.restype = vp
+    lib.zro_scene_create.argtypes = [C.POINTER(capi.SceneDesc)]
+    lib.zro_scene_destroy.argtypes = [vp]
+    lib.zro_render.argtypes = [vp, C.POINTER(capi.Camera), C.POINTER(capi.Env), C.c_uint64, C.POINTER(capi.Region),
+                               C.c_int, vp, vp, vp, C.POINTER(capi.Counters)]
+    lib.zro_trace.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, vp]
+    lib.zro_scatter.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    _lib = lib
+    return lib
+
+
+class OracleScene:
+    """The CPU restatement over a flattened scene (the arrays must outlive this object)."""
+
+    def __init__(self, desc):
+        self.lib = load()
+        self._keep = desc
+        self._s = self.lib.zro_scene_create(C.byref(desc))
+
+    def render(self, camera, env, seed, region=None, threads=None, per_sample=False):
+        """Returns (frame[H,W,3], counters, samples[h,w,spp,3] | None, counts[h,w,spp,2] | None)."""
+        h, w, spp = camera.image_height, camera.image_width, camera.samples_per_pixel
+        out = np.zeros((h, w, 3), dtype=np.float64)
+        rw, rh = (region.w, region.h) if region is not None and region.w > 0 else (w, h)
+        samples = np.zeros((rh, rw, spp, 3), dtype=np.float64) if per_sample else None
+        counts = np.zeros((rh, rw, spp, 2), dtype=np.uint32) if per_sample else None
+        ctr = capi.Counters()
+        threads = threads or min(16, os.cpu_count() or 1)
+        rc = self.lib.zro_render(self._s, C.byref(camera), C.byref(env), C.c_uint64(seed),
+                                 C.byref(region) if region is not None else None, threads, out.ctypes.data,
+                                 samples.ctypes.data if per_sample else None, counts.ctypes.data if per_sample else None,
+                                 C.byref(ctr))
+        if rc != 0:
+            raise RuntimeError(f"oracle render failed: {rc}")
+        return out, ctr, samples, counts
+
+    def trace(self, rays, tmin=0.001, tmax=float("inf"), seed=1, pixel=0x7ACE, bounce=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float64)
+        out = np.zeros(rays.shape[0], dtype=capi.HIT_DTYPE)
+        self.lib.zro_trace(self._s, rays.ctypes.data, rays.shape[0], tmin, tmax, C.c_uint64(seed), C.c_uint64(pixel), bounce,
+                           out.ctypes.data)
+        return out
+
+    def scatter(self, ray, hit, key):
+        att = np.zeros(3); out = np.zeros(6)
+        ray = np.ascontiguousarray(ray, dtype=np.float64)
+        h = np.ascontiguousarray(hit)
+        ok = self.lib.zro_scatter(self._s, ray.ctypes.data, h.ctypes.data, C.c_uint64(key), att.ctypes.data, out.ctypes.data)
+        return bool(ok), att, out
+
+    def close(self):
+        if self._s:
+            self.lib.zro_scene_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ref_available():
+    return os.path.exists(REF_BIN) and os.access(REF_BIN, os.X_OK)
+
+
+def ref_run(*args, timeout=3600):
+    """Runs the genuine-reference harness (prebuilt in this container from /root/reference) and parses its JSON line."""
+    p = subprocess.run([REF_BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, check=True)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+MASK64 = (1 << 64) - 1
+
+
+def mix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def stream_key(seed, pixel, sample):
+    g = 0x9E3779B97F4A7C15
+    return mix64((mix64((seed + g * (pixel + 1)) & MASK64) + g * (sample + 1)) & MASK64)

@@ -1,0 +1,586 @@
+// zr_device.h — device-side data layout (HBM) and the per-ray arithmetic of the integrator, written for
+// gfx950 (wave64).  FP64 throughout, as the reference (vec3 = 3 x double, /root/reference/vec3.hpp:7-115):
+// every accept/reject decision of the reference is a double comparison and one flipped decision moves a
+// pixel by ~1/spp >> the 1e-4 parity bound, so decisions are taken in FP64.  Only the BVH child boxes are
+// FP32 (rounded outwards and padded): testing a superset of boxes cannot change the closest primitive.
+//
+// Each function names the reference code whose result it reproduces.  Nothing here is reference code:
+// traversal is deferred-record (the BVH walk keeps only (t, leaf object) and the hit record of the winner
+// is reconstructed once), which the reference's recursive virtual calls cannot do.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/zr_capi.h"
+#include "../../include/zr_rng.h"
+
+#include "zr_device_types.h"
+
+namespace zr {
+
+// ---- small vector algebra (same operation order as vec3.hpp) --------------------------------------
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(double t, V3 v) { return mk(t * v.x, t * v.y, t * v.z); }
+__device__ __forceinline__ V3 operator*(V3 v, double t) { return mk(t * v.x, t * v.y, t * v.z); }
+__device__ __forceinline__ V3 vdiv(V3 v, double t) { double r = 1 / t; return mk(r * v.x, r * v.y, r * v.z); }  // vec3 operator/
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ double len(V3 a) { return sqrt(len2(a)); }
+__device__ __forceinline__ V3 unit(V3 v) { double l = len(v); if (l < 1e-8) return mk(0, 0, 0); return vdiv(v, l); }
+__device__ __forceinline__ double get(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (hi < v ? hi : v); }
+
+struct Ray { V3 o, d; };
+__device__ __forceinline__ V3 at(const Ray& r, double t) { return r.o + t * r.d; }
+
+struct Rec {
+    V3 p, n, tan, bit;
+    double t, u, v;
+    uint32_t mat;
+    bool front;
+};
+__device__ __forceinline__ void set_face(Rec& rec, V3 rd, V3 outward) {  // hittable.hpp:22-25
+    rec.front = dot(rd, outward) < 0;
+    rec.n = rec.front ? outward : -outward;
+}
+
+struct Rng {
+    uint64_t key, k;
+    uint32_t bounce;
+    __device__ __forceinline__ double next() { return zr_bits_to_unit(zr_stream_bits(key, k++)); }
+    __device__ __forceinline__ double range(double a, double b) { return a + (b - a) * next(); }
+};
+
+__device__ inline V3 random_unit_vector(Rng& g) {  // vec3.hpp:184-191
+    for (;;) {
+        double x = g.range(-1, 1);
+        double y = g.range(-1, 1);
+        double z = g.range(-1, 1);
+        V3 p = mk(x, y, z);
+        double l2 = len2(p);
+        if (1e-160 < l2 && l2 <= 1) return vdiv(p, sqrt(l2));
+    }
+}
+
+struct Counters { uint32_t nodes, sph, tri, cube, med; };
+
+// ---- wrapper chain: ray into object space (translate/rotate_*/scale ::hit, first halves) -----------
+__device__ inline void apply_op_ray(const zr_xform_op& op, Ray& r) {
+    switch (op.kind) {
+        case ZR_OP_TRANSLATE: r.o = r.o - mk(op.a[0], op.a[1], op.a[2]); break;
+        case ZR_OP_ROTATE_Y: {
+            double s = op.a[0], c = op.a[1];
+            double ox = c * r.o.x + s * r.o.z, oz = -s * r.o.x + c * r.o.z;
+            double dx = c * r.d.x + s * r.d.z, dz = -s * r.d.x + c * r.d.z;
+            r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+        } break;
+        case ZR_OP_ROTATE_X: {
+            double s = op.a[0], c = op.a[1];
+            double oy = c * r.o.y + s * r.o.z, oz = -s * r.o.y + c * r.o.z;
+            double dy = c * r.d.y + s * r.d.z, dz = -s * r.d.y + c * r.d.z;
+            r.o.y = oy; r.o.z = oz; r.d.y = dy; r.d.z = dz;
+        } break;
+        case ZR_OP_ROTATE_Z: {
+            double s = op.a[0], c = op.a[1];
+            double ox = c * r.o.x + s * r.o.y, oy = -s * r.o.x + c * r.o.y;
+            double dx = c * r.d.x + s * r.d.y, dy = -s * r.d.x + c * r.d.y;
+            r.o.x = ox; r.o.y = oy; r.d.x = dx; r.d.y = dy;
+        } break;
+        case ZR_OP_SCALE:
+            r.o = mk(r.o.x / op.a[0], r.o.y / op.a[1], r.o.z / op.a[2]);
+            r.d = mk(r.d.x / op.a[0], r.d.y / op.a[1], r.d.z / op.a[2]);
+            break;
+        default: break;  // ZR_OP_MATERIAL
+    }
+}
+__device__ inline Ray chain_ray(const DScene& sc, uint32_t cf, uint32_t upto, Ray r) {
+    for (uint32_t k = 0; k < upto; k++) apply_op_ray(sc.ops[cf + k], r);
+    return r;
+}
+// second halves: hit record back to the wrapper's outer space.  rd_outer = direction of the ray the
+// wrapper itself received.
+__device__ inline void apply_op_rec(const zr_xform_op& op, V3 rd_outer, Rec& rec) {
+    switch (op.kind) {
+        case ZR_OP_TRANSLATE:  // translate.hpp:27-29
+            rec.p = rec.p + mk(op.a[0], op.a[1], op.a[2]);
+            set_face(rec, rd_outer, rec.n);
+            break;
+        case ZR_OP_ROTATE_Y: {  // rotate_y.hpp:58-70
+            double s = op.a[0], c = op.a[1];
+            V3 p = rec.p, n = rec.n;
+            p.x = c * rec.p.x - s * rec.p.z; p.z = s * rec.p.x + c * rec.p.z;
+            n.x = c * rec.n.x - s * rec.n.z; n.z = s * rec.n.x + c * rec.n.z;
+            rec.p = p;
+            set_face(rec, rd_outer, n);
+        } break;
+        case ZR_OP_ROTATE_X: {  // rotate_x.hpp:57-67: front_face not refreshed
+            double s = op.a[0], c = op.a[1];
+            V3 p = rec.p, n = rec.n;
+            p.y = c * rec.p.y - s * rec.p.z; p.z = s * rec.p.y + c * rec.p.z;
+            n.y = c * rec.n.y - s * rec.n.z; n.z = s * rec.n.y + c * rec.n.z;
+            rec.p = p; rec.n = n;
+        } break;
+        case ZR_OP_ROTATE_Z: {  // rotate_z.hpp:54-64
+            double s = op.a[0], c = op.a[1];
+            V3 p = rec.p, n = rec.n;
+            p.x = c * rec.p.x - s * rec.p.y; p.y = s * rec.p.x + c * rec.p.y;
+            n.x = c * rec.n.x - s * rec.n.y; n.y = s * rec.n.x + c * rec.n.y;
+            rec.p = p; rec.n = n;
+        } break;
+        case ZR_OP_SCALE:  // scale.hpp:29-33
+            rec.p = mk(rec.p.x * op.a[0], rec.p.y * op.a[1], rec.p.z * op.a[2]);
+            rec.n = unit(mk(rec.n.x / op.a[0], rec.n.y / op.a[1], rec.n.z / op.a[2]));
+            break;
+        default:  // material_instance.hpp:19-21
+            rec.mat = op.mat;
+            break;
+    }
+}
+
+// ---- primitives: distance only (used while walking the tree) ---------------------------------------
+// sphere.hpp:18-40.  surrounds(): strict on both ends.
+__device__ __forceinline__ bool sphere_t(const double* s, const Ray& r, double tmin, double tmax, double& t) {
+    V3 oc = mk(s[0], s[1], s[2]) - r.o;
+    double a = len2(r.d);
+    double h = dot(r.d, oc);
+    double c = len2(oc) - s[3] * s[3];
+    double disc = h * h - a * c;
+    if (disc < 0) return false;
+    double sq = sqrt(disc);
+    double root = (h - sq) / a;
+    if (!(tmin < root && tmax > root)) {
+        root = (h + sq) / a;
+        if (!(tmin < root && tmax > root)) return false;
+    }
+    t = root;
+    return true;
+}
+
+// triangle.hpp:17-57.  contains(): inclusive.  Outputs what the record needs so it is not recomputed.
+__device__ __forceinline__ bool triangle_t(const double* v, const Ray& r, double tmin, double tmax, double& t) {
+    V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+    V3 normal = cross(v1 - v0, v2 - v0);
+    double nl = len(normal);
+    if (nl < 1e-8) return false;
+    V3 un = vdiv(normal, nl);
+    double nd = dot(un, r.d);
+    if (fabs(nd) < 1e-8) return false;
+    double D = dot(un, v0);
+    double tt = (D - dot(un, r.o)) / nd;
+    if (!(tmin <= tt && tt <= tmax)) return false;
+    V3 p = at(r, tt);
+    V3 C0 = cross(v1 - v0, p - v0);
+    V3 C1 = cross(v2 - v1, p - v1);
+    V3 C2 = cross(v0 - v2, p - v2);
+    if (dot(normal, C0) < 0 || dot(normal, C1) < 0 || dot(normal, C2) < 0) return false;
+    t = tt;
+    return true;
+}
+
+// cube.hpp:44-73 (slabs about the ORIGIN, not the centre: cube.hpp:57-58)
+__device__ __forceinline__ bool cube_t(const double* q, const Ray& r, double tmin, double tmax, double& t) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double he = q[i];
+        double inv = 1.0 / get(r.d, i);
+        double o = get(r.o, i);
+        double t0 = (-he - o) * inv;
+        double t1 = (he - o) * inv;
+        if (inv < 0.0) { double x = t0; t0 = t1; t1 = x; }
+        tmin = fmax(t0, tmin);
+        tmax = fmin(t1, tmax);
+        if (tmax < tmin) return false;
+    }
+    t = tmin;
+    return true;
+}
+
+__device__ inline bool bare_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, double& t) {
+    if (kind == ZR_PRIM_SPHERE) return sphere_t(sc.spheres + (size_t)idx * 4, r, tmin, tmax, t);
+    if (kind == ZR_PRIM_CUBE) return cube_t(sc.cubes + (size_t)idx * 6, r, tmin, tmax, t);
+    return triangle_t(sc.tri_v + (size_t)idx * 9, r, tmin, tmax, t);
+}
+
+// constant_medium.hpp:39-77, distance only
+__device__ inline bool medium_t(const DScene& sc, uint32_t idx, const Ray& r, double tmin, double tmax, const Rng& g, double& t) {
+    const DMedium& m = sc.media[idx];
+    Ray br = chain_ray(sc, m.chain_first, m.chain_count, r);
+    double t1, t2;
+    const double inf = __builtin_huge_val();
+    if (!bare_t(sc, m.btype, m.bindex, br, -inf, inf, t1)) return false;
+    if (!bare_t(sc, m.btype, m.bindex, br, t1 + 0.0001, inf, t2)) return false;
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    double rl = len(r.d);
+    double inside = (t2 - t1) * rl;
+    double xi = zr_bits_to_unit(zr_medium_bits(g.key, g.bounce, m.id));
+    double hd = m.neg_inv_density * log(xi);
+    if (hd > inside) return false;
+    t = t1 + hd / rl;
+    return true;
+}
+
+// any leaf object
+__device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, const Rng& g,
+                                double& t) {
+    if (kind == ZR_KIND_WRAPPED) {
+        const DWrapped w = sc.wrapped[idx];
+        Ray lr = chain_ray(sc, w.chain_first, w.chain_count, r);
+        if (w.type == ZR_PRIM_MEDIUM) return medium_t(sc, w.index, lr, tmin, tmax, g, t);
+        return bare_t(sc, w.type, w.index, lr, tmin, tmax, t);
+    }
+    if (kind == ZR_PRIM_MEDIUM) return medium_t(sc, idx, r, tmin, tmax, g, t);
+    return bare_t(sc, kind, idx, r, tmin, tmax, t);
+}
+
+// ---- primitives: full hit record of the winner ------------------------------------------------------
+__device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // sphere.hpp:42-79
+    const double* s = sc.spheres + (size_t)idx * 4;
+    V3 center = mk(s[0], s[1], s[2]);
+    rec.t = t;
+    rec.p = at(r, t);
+    V3 outward = vdiv(rec.p - center, s[3]);
+    set_face(rec, r.d, outward);
+    double theta = acos(-outward.y);
+    double phi = atan2(-outward.z, outward.x) + 3.14159265358979323846;
+    rec.u = phi / (2 * 3.14159265358979323846);
+    rec.v = theta / 3.14159265358979323846;
+    rec.tan = cross(mk(0, 1, 0), rec.n);
+    if (len2(rec.tan) < 0.001) rec.tan = cross(mk(0, 0, 1), rec.n);
+    rec.tan = unit(rec.tan);
+    rec.bit = cross(rec.n, rec.tan);
+    rec.mat = sc.sphere_mat[idx];
+}
+
+__device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // triangle.hpp:40-79
+    const double* v = sc.tri_v + (size_t)idx * 9;
+    const double* nn = sc.tri_n + (size_t)idx * 9;
+    V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+    V3 normal = cross(v1 - v0, v2 - v0);
+    V3 p = at(r, t);
+    V3 C0 = cross(v1 - v0, p - v0);
+    V3 C2 = cross(v0 - v2, p - v2);
+    double area2 = dot(normal, normal);
+    double u = dot(normal, C2) / area2;
+    double w_ = dot(normal, C0) / area2;
+    double w0 = 1.0 - u - w_;
+    V3 smooth = unit(w0 * ld3(nn) + u * ld3(nn + 3) + w_ * ld3(nn + 6));
+    rec.t = t;
+    rec.p = p;
+    rec.mat = sc.tri_mat[idx];
+    set_face(rec, r.d, smooth);
+    // u, v, tangent, bitangent are not written by triangle::hit: fresh-record values
+    rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
+}
+
+__device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // cube.hpp:73-142
+    const double* q = sc.cubes + (size_t)idx * 6;
+    V3 he = ld3(q), center = ld3(q + 3);
+    rec.t = t;
+    rec.p = at(r, t);
+    V3 p = rec.p - center;
+    const double EPS = 1e-3;
+    if (fabs(p.x + he.x) < EPS) {
+        rec.n = mk(-1, 0, 0); rec.u = (p.z + he.z) / (2 * he.z); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(0, 0, 1);
+    } else if (fabs(p.x - he.x) < EPS) {
+        rec.n = mk(1, 0, 0); rec.u = (p.z + he.z) / (2 * he.z); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(0, 0, -1);
+    } else if (fabs(p.y + he.y) < EPS) {
+        rec.n = mk(0, -1, 0); rec.u = (p.x + he.x) / (2 * he.x); rec.v = (p.z + he.z) / (2 * he.z); rec.tan = mk(1, 0, 0);
+    } else if (fabs(p.y - he.y) < EPS) {
+        rec.n = mk(0, 1, 0); rec.u = (p.x + he.x) / (2 * he.x); rec.v = (p.z + he.z) / (2 * he.z); rec.tan = mk(-1, 0, 0);
+    } else if (fabs(p.z + he.z) < EPS) {
+        rec.n = mk(0, 0, -1); rec.u = (he.x - p.x) / (2 * he.x); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(-1, 0, 0);
+    } else {
+        rec.n = mk(0, 0, 1); rec.u = (p.x + he.x) / (2 * he.x); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(1, 0, 0);
+    }
+    rec.bit = cross(rec.n, rec.tan);
+    rec.mat = sc.cube_mat[idx];
+    set_face(rec, r.d, rec.n);
+}
+
+__device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec) {
+    if (kind == ZR_PRIM_SPHERE) sphere_rec(sc, idx, r, t, rec);
+    else if (kind == ZR_PRIM_CUBE) cube_rec(sc, idx, r, t, rec);
+    else if (kind == ZR_PRIM_TRIANGLE) triangle_rec(sc, idx, r, t, rec);
+    else {  // medium: constant_medium.hpp:70-75
+        rec.t = t;
+        rec.p = at(r, t);
+        rec.n = mk(1, 0, 0);
+        rec.front = true;
+        rec.mat = sc.media[idx].mat;
+        rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
+    }
+}
+
+// hit record of leaf object (kind, idx) hit by world ray r at distance t
+__device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec) {
+    if (kind != ZR_KIND_WRAPPED) { bare_rec(sc, kind, idx, r, t, rec); return; }
+    const DWrapped w = sc.wrapped[idx];
+    Ray lr = chain_ray(sc, w.chain_first, w.chain_count, r);
+    bare_rec(sc, w.type, w.index, lr, t, rec);
+    for (int k = (int)w.chain_count - 1; k >= 0; k--) {
+        Ray outer = chain_ray(sc, w.chain_first, (uint32_t)k, r);
+        apply_op_rec(sc.ops[w.chain_first + k], outer.d, rec);
+    }
+}
+
+// ---- closest hit: BVH walk (replaces bvh_node::hit, bvh.hpp:46-54,112-118 + aabb::hit, aabb.hpp:44-66) ----
+// `stack` is this lane's column of the workgroup's LDS traversal stack: entry i lives at stack[i * stride].
+// Returns the leaf object and distance of the closest hit in (tmin, +inf).
+template <bool COUNT>
+__device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, const Rng& g, uint32_t* stack, int stride,
+                                   double& t_out, uint32_t& kind_out, uint32_t& idx_out, Counters& ctr) {
+    const double idx_ = 1.0 / r.d.x, idy_ = 1.0 / r.d.y, idz_ = 1.0 / r.d.z;
+    const double ox_ = r.o.x * idx_, oy_ = r.o.y * idy_, oz_ = r.o.z * idz_;
+    double tbest = __builtin_huge_val();
+    uint32_t kbest = 0xFFFFFFFFu, ibest = 0;
+    int sp = 0;
+    uint32_t cur = 0;  // NodePair index
+    for (;;) {
+        const NodePair* np = sc.nodes + cur;
+        // one 64-B record: 4 x 16-B loads
+        const float4 q0 = reinterpret_cast<const float4*>(np)[0];
+        const float4 q1 = reinterpret_cast<const float4*>(np)[1];
+        const float4 q2 = reinterpret_cast<const float4*>(np)[2];
+        const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+        // lo[0] = q0.xyz, lo[1] = q0.w q1.xy, hi[0] = q1.zw q2.x, hi[1] = q2.yzw
+        if (COUNT) ctr.nodes += 2;
+        double tn[2], tf[2];
+        {
+            double a0 = fma((double)q0.x, idx_, -ox_), a1 = fma((double)q1.z, idx_, -ox_);
+            double b0 = fma((double)q0.y, idy_, -oy_), b1 = fma((double)q1.w, idy_, -oy_);
+            double c0 = fma((double)q0.z, idz_, -oz_), c1 = fma((double)q2.x, idz_, -oz_);
+            tn[0] = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), tmin));
+            tf[0] = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
+        }
+        {
+            double a0 = fma((double)q0.w, idx_, -ox_), a1 = fma((double)q2.y, idx_, -ox_);
+            double b0 = fma((double)q1.x, idy_, -oy_), b1 = fma((double)q2.z, idy_, -oy_);
+            double c0 = fma((double)q1.y, idz_, -oz_), c1 = fma((double)q2.w, idz_, -oz_);
+            tn[1] = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), tmin));
+            tf[1] = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
+        }
+        // a NaN slab (0 * inf) makes fmin/fmax ignore that slab: conservative
+        bool h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1];
+        const uint32_t c[2] = {q3.x, q3.y};
+        const uint32_t m[2] = {q3.z, q3.w};
+        // leaves first: they can only shrink tbest
+        uint32_t next = 0xFFFFFFFFu, defer = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            bool h = s == 0 ? h0 : h1;
+            if (!h) continue;
+            if (m[s] != 0) {
+                uint32_t kind = (m[s] >> 16) - 1, cnt = m[s] & 0xFFFFu;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    double t;
+                    if (COUNT) {
+                        uint32_t kk = kind;
+                        if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[c[s] + k].type;
+                        if (kk == ZR_PRIM_SPHERE) ctr.sph++; else if (kk == ZR_PRIM_TRIANGLE) ctr.tri++; else if (kk == ZR_PRIM_CUBE) ctr.cube++; else ctr.med++;
+                    }
+                    if (object_t(sc, kind, c[s] + k, r, tmin, tbest, g, t)) { tbest = t; kbest = kind; ibest = c[s] + k; }
+                }
+            } else {
+                if (next == 0xFFFFFFFFu) next = c[s]; else defer = c[s];
+            }
+        }
+        if (defer != 0xFFFFFFFFu) {
+            // both children are internal and hit: descend into the nearer one first
+            if (tn[1] < tn[0]) { uint32_t x = next; next = defer; defer = x; }
+            stack[sp * stride] = defer; sp++;
+        }
+        if (next == 0xFFFFFFFFu) {
+            if (sp == 0) break;
+            sp--; next = stack[sp * stride];
+        }
+        cur = next;
+    }
+    t_out = tbest; kind_out = kbest; idx_out = ibest;
+    return kbest != 0xFFFFFFFFu;
+}
+
+// ---- textures (texture.hpp:50-78, 96-98, 118-126) -----------------------------------------------------
+__device__ inline V3 tex_value(const DScene& sc, uint32_t id, double u, double v, V3 p) {
+    for (int guard = 0; guard < 16; guard++) {
+        const zr_texture& t = sc.texs[id];
+        if (t.kind == ZR_TEX_SOLID) return mk(t.color[0], t.color[1], t.color[2]);
+        if (t.kind == ZR_TEX_CHECKER) {
+            int xi = (int)floor(t.inv_scale * p.x);
+            int yi = (int)floor(t.inv_scale * p.y);
+            int zi = (int)floor(t.inv_scale * p.z);
+            bool even = (xi + yi + zi) % 2 == 0;
+            id = even ? t.even : t.odd;
+            continue;
+        }
+        if (t.width == 0 || t.height == 0) return mk(0.0, 1.0, 1.0);
+        int width = (int)t.width, height = (int)t.height;
+        u = u - floor(u);
+        int i = (int)(u * width);
+        int j = (int)(v * height);
+        i = i < 0 ? 0 : (i > width - 1 ? width - 1 : i);
+        j = j < 0 ? 0 : (j > height - 1 ? height - 1 : j);
+        const unsigned char* base = sc.texels + t.texel_offset;
+        size_t o = ((size_t)j * width + i) * 3;
+        if (t.kind == ZR_TEX_IMAGE_F32) {
+            const float* px = (const float*)base + o;
+            return mk((double)px[0], (double)px[1], (double)px[2]);
+        }
+        const double s = 1.0 / 255.0;
+        const unsigned char* px = base + o;
+        return mk(s * px[0], s * px[1], s * px[2]);
+    }
+    return mk(0, 0, 0);
+}
+
+__device__ inline V3 bumped_normal(const DScene& sc, const Rec& rec, uint32_t bump, double strength) {  // material.hpp:35-54
+    double du = 1.0 / 1024.0, dv = 1.0 / 1024.0;
+    double hc = tex_value(sc, bump, rec.u, rec.v, rec.p).x;
+    double hu = tex_value(sc, bump, rec.u + du, rec.v, rec.p).x;
+    double hv = tex_value(sc, bump, rec.u, rec.v + dv, rec.p).x;
+    double fu = (hu - hc) * strength;
+    double fv = (hv - hc) * strength;
+    return unit(rec.n - (fu * rec.tan) - (fv * rec.bit));
+}
+
+// ---- materials --------------------------------------------------------------------------------------
+__device__ inline V3 reflect(V3 v, V3 n) { return v - (2 * dot(v, n)) * n; }
+
+__device__ inline V3 emitted(const DScene& sc, const Rec& rec) {  // material.hpp:12-14, 261-263
+    if (rec.mat >= sc.n_mats) return mk(0, 0, 0);
+    const zr_material& m = sc.mats[rec.mat];
+    if (m.kind == ZR_MAT_LIGHT) return tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+    return mk(0, 0, 0);
+}
+
+// returns false when the path ends (absorbed / light).  A null material (UB in the reference) absorbs.
+__device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec, V3& att, Ray& out, Rng& g) {
+    if (rec.mat >= sc.n_mats) return false;
+    const zr_material& m = sc.mats[rec.mat];
+    switch (m.kind) {
+        case ZR_MAT_LAMBERTIAN: {  // material.hpp:74-96
+            V3 wn = rec.n;
+            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
+            V3 dir = wn + random_unit_vector(g);
+            if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = wn;
+            out.o = rec.p + (rec.n * 0.0001);
+            out.d = dir;
+            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            return true;
+        }
+        case ZR_MAT_METAL: {  // material.hpp:129-151
+            V3 wn = rec.n;
+            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
+            V3 v = unit(rin.d);
+            V3 refl = reflect(v, wn);
+            V3 dir = unit(refl + (m.param * random_unit_vector(g)));
+            out.o = rec.p + (0.0001 * rec.n);
+            out.d = dir;
+            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            return dot(dir, rec.n) > 0;
+        }
+        case ZR_MAT_DIELECTRIC: {  // material.hpp:192-224, 237-241
+            att = mk(m.tint[0], m.tint[1], m.tint[2]);
+            V3 wn = rec.n;
+            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
+            double ri = rec.front ? (1.0 / m.param) : m.param;
+            V3 ud = unit(rin.d);
+            double ct = fmin(dot(-ud, wn), 1.0);
+            double st = sqrt(1.0 - ct * ct);
+            bool refl = ri * st > 1.0;
+            if (!refl) {
+                double r0 = (1 - ri) / (1 + ri);
+                r0 = r0 * r0;
+                double rf = r0 + (1 - r0) * pow(1 - ct, 5.0);
+                refl = rf > g.next();
+            }
+            V3 dir;
+            if (refl) dir = reflect(ud, wn);
+            else {  // refract, vec3.hpp:209-214
+                double c2 = fmin(dot(-ud, wn), 1.0);
+                V3 perp = ri * (ud + c2 * wn);
+                V3 par = (-sqrt(fabs(1.0 - len2(perp)))) * wn;
+                dir = perp + par;
+            }
+            V3 off = (dot(dir, rec.n) > 0) ? (0.0001 * rec.n) : (-0.0001 * rec.n);
+            out.o = rec.p + off;
+            out.d = dir;
+            return true;
+        }
+        case ZR_MAT_ISOTROPIC: {  // constant_medium.hpp:14-18
+            out.o = rec.p;
+            out.d = random_unit_vector(g);
+            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            return true;
+        }
+        default: return false;  // diffuse_light, material.hpp:255-259
+    }
+}
+
+// ---- background (camera.hpp:828-925) -------------------------------------------------------------------
+__device__ inline V3 background(const DScene& sc, const DEnv& env, V3 rd) {
+    if (env.mode == ZR_ENV_SOLID_COLOR) return mk(env.solid[0], env.solid[1], env.solid[2]);
+    V3 ud = unit(rd);
+    if (env.mode == ZR_ENV_HDR_MAP) {
+        if (env.hdr_tex == ZR_NO_TEXTURE) return mk(0, 0, 0);
+        V3 d = ud;
+        double x1 = env.cy * d.x + env.sy * d.z;
+        double z1 = -env.sy * d.x + env.cy * d.z;
+        d = mk(x1, d.y, z1);
+        double y2 = env.cp * d.y - env.sp * d.z;
+        double z2 = env.sp * d.y + env.cp * d.z;
+        d = mk(d.x, y2, z2);
+        double x3 = env.cr * d.x - env.sr * d.y;
+        double y3 = env.sr * d.x + env.cr * d.y;
+        d = mk(x3, y3, d.z);
+        const double PI = 3.14159265358979323846;
+        double phi = atan2(d.z, d.x) + PI;
+        double theta = acos(clampd(d.y, -1.0, 1.0));
+        return tex_value(sc, env.hdr_tex, phi / (2 * PI), theta / PI, mk(0, 0, 0)) * env.intensity;
+    }
+    V3 hor = mk(env.horizon[0], env.horizon[1], env.horizon[2]);
+    V3 zen = mk(env.zenith[0], env.zenith[1], env.zenith[2]);
+    V3 sun = mk(env.sun[0], env.sun[1], env.sun[2]);
+    double a = ud.y;
+    V3 sky;
+    if (a > 0.0) sky = (1.0 - a) * hor + a * zen; else sky = hor * 0.1;
+    V3 fin = (sky * env.sky_scale) * env.sky_exposure;
+    double focus = dot(ud, sun);
+    if (env.sun_on && focus > env.sun_thr) {
+        double x = clampd((focus - env.sun_thr) / ((env.sun_thr + 0.0002) - env.sun_thr), 0.0, 1.0);  // smoothstep, common.hpp:87-91
+        double alpha = x * x * (3 - 2 * x);
+        fin = fin + mk(env.sun_add[0], env.sun_add[1], env.sun_add[2]) * alpha;
+    }
+    return fin;
+}
+
+// ---- camera ray (camera.hpp:784-794, 817-825) -----------------------------------------------------------
+__device__ inline Ray camera_ray(const DCamera& cam, int i, int j, Rng& g) {
+    double ox = g.next() - 0.5;
+    double oy = g.next() - 0.5;
+    V3 ps = ld3(cam.pixel00) + ((i + ox) * ld3(cam.du)) + ((j + oy) * ld3(cam.dv));
+    V3 org = ld3(cam.center);
+    if (cam.defocus) {
+        double px, py;
+        for (;;) {  // random_in_unit_disk, vec3.hpp:174-181
+            px = g.range(-1, 1);
+            py = g.range(-1, 1);
+            if (px * px + py * py + 0.0 * 0.0 < 1) break;
+        }
+        org = ld3(cam.center) + (px * ld3(cam.disk_u)) + (py * ld3(cam.disk_v));
+    }
+    Ray r; r.o = org; r.d = ps - org;
+    return r;
+}
+
+}  // namespace zr

@@ -1,0 +1,763 @@
+// zr_host.cpp — implementation of the C ABI (include/zr_capi.h): scene ingest, BVH build, HBM upload,
+// render driver.  Plain C++ (host compiler, -ffp-contract=off so that the camera frame and the sky
+// constants are computed with exactly the reference's operation order, camera.hpp:358-399, 874-895,914);
+// the kernels live in zr_kernels.hip.  There is deliberately no CPU rendering path in this library:
+// without a HIP device zr_create() fails and says so.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/zr_capi.h"
+#include "zr_bvh.h"
+#include "zr_device_types.h"
+#include "zr_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_OK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(ZR_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+const double kInf = std::numeric_limits<double>::infinity();
+const double kPi = 3.14159265358979323846;
+
+struct H3 { double x, y, z; };
+inline H3 h3(const double* p) { return H3{p[0], p[1], p[2]}; }
+inline H3 operator+(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 operator-(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 operator-(H3 a) { return H3{-a.x, -a.y, -a.z}; }
+inline H3 operator*(double t, H3 v) { return H3{t * v.x, t * v.y, t * v.z}; }
+inline H3 operator*(H3 v, double t) { return t * v; }
+inline H3 operator/(H3 v, double t) { return (1 / t) * v; }  // vec3.hpp:149-151
+inline H3 cross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double len(H3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline H3 unit(H3 v) { double l = len(v); if (l < 1e-8) return H3{0, 0, 0}; return v / l; }
+inline void st3(double* d, H3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (hi < v ? hi : v); }
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int upload(const std::vector<T>& v) {
+        release();
+        n = v.size();
+        size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 64);  // never a null device pointer
+        HIP_OK(hipMalloc((void**)&p, bytes));
+        if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+        return ZR_OK;
+    }
+    int alloc(size_t count) {
+        if (count == n && p) return ZR_OK;
+        release();
+        n = count;
+        HIP_OK(hipMalloc((void**)&p, std::max<size_t>(sizeof(T) * count, 64)));
+        return ZR_OK;
+    }
+};
+
+}  // namespace
+
+struct zr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<unsigned long long> d_ctr;
+    DevBuf<double> d_out;
+    DevBuf<int32_t> d_tiles;
+    std::vector<hipEvent_t> ev;       // start/stop pairs of the last render's launches
+    size_t ev_used = 0;
+    hipStream_t last_stream = nullptr;
+    bool last_counted = false;
+    std::vector<float> last_ms;
+    bool times_resolved = true;
+};
+
+struct zr_scene {
+    zr_ctx* ctx = nullptr;
+    // host copies (as given)
+    std::vector<double> spheres, tri_v, tri_n, cubes;
+    std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
+    std::vector<zr_medium> media;
+    std::vector<zr_xform_op> ops;
+    std::vector<zr_object> objects;
+    bool objects_set = false;
+    std::vector<zr_material> materials;
+    std::vector<zr_texture> textures;
+    std::vector<unsigned char> texels;
+    // device
+    bool committed = false;
+    DevBuf<zr::NodePair> d_nodes;
+    DevBuf<double> d_spheres, d_tri_v, d_tri_n, d_cubes;
+    DevBuf<uint32_t> d_sphere_mat, d_tri_mat, d_cube_mat;
+    DevBuf<zr::DMedium> d_media;
+    DevBuf<zr::DWrapped> d_wrapped;
+    DevBuf<zr_xform_op> d_ops;
+    DevBuf<zr_material> d_mats;
+    DevBuf<zr_texture> d_texs;
+    DevBuf<unsigned char> d_texels;
+    zr::DScene ds{};
+    uint64_t stats[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+// ---- bounding boxes of world-list entries, following the reference's constructors --------------------
+struct Boxer {
+    const zr_scene& s;
+    zr::BuildBox prim(uint32_t type, uint32_t idx) const {
+        zr::BuildBox b;
+        if (type == ZR_PRIM_SPHERE) {  // sphere.hpp:12-14 (raw radius argument)
+            const double* q = &s.spheres[(size_t)idx * 4];
+            for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(q[k] - q[3], q[k] + q[3]); b.hi[k] = std::fmax(q[k] - q[3], q[k] + q[3]); }
+        } else if (type == ZR_PRIM_TRIANGLE) {  // triangle.hpp:84-101
+            const double* v = &s.tri_v[(size_t)idx * 9];
+            for (int k = 0; k < 3; k++) {
+                b.lo[k] = std::fmin(v[k], std::fmin(v[3 + k], v[6 + k]));
+                b.hi[k] = std::fmax(v[k], std::fmax(v[3 + k], v[6 + k]));
+                if (b.hi[k] - b.lo[k] < 0.0001) { b.lo[k] -= 0.0001; b.hi[k] += 0.0001; }
+            }
+        } else if (type == ZR_PRIM_CUBE) {  // cube.hpp:34-41
+            const double* q = &s.cubes[(size_t)idx * 12];
+            for (int k = 0; k < 3; k++) { b.lo[k] = q[6 + k] - 0.00005; b.hi[k] = q[9 + k] + 0.00005; }
+        } else {  // constant_medium.hpp:79-81
+            const zr_medium& m = s.media[idx];
+            b = chain(m.boundary_type, m.boundary_index, m.chain_first, m.chain_count);
+        }
+        return b;
+    }
+    zr::BuildBox chain(uint32_t type, uint32_t idx, uint32_t cf, uint32_t cn) const {
+        if (cn == 0) return prim(type, idx);
+        zr::BuildBox in = chain(type, idx, cf + 1, cn - 1), b;
+        const zr_xform_op& op = s.ops[cf];
+        if (op.kind == ZR_OP_TRANSLATE) {  // translate.hpp:12
+            for (int k = 0; k < 3; k++) { b.lo[k] = in.lo[k] + op.a[k]; b.hi[k] = in.hi[k] + op.a[k]; }
+            return b;
+        }
+        if (op.kind == ZR_OP_SCALE) {  // scale.hpp:11-17
+            for (int k = 0; k < 3; k++) { double a0 = in.lo[k] * op.a[k], a1 = in.hi[k] * op.a[k]; b.lo[k] = std::fmin(a0, a1); b.hi[k] = std::fmax(a0, a1); }
+            return b;
+        }
+        if (op.kind == ZR_OP_MATERIAL) return in;
+        for (int k = 0; k < 3; k++) { b.lo[k] = kInf; b.hi[k] = -kInf; }
+        const double sn = op.a[0], co = op.a[1];  // rotate_*.hpp constructors: the 8 corners
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+            double x = i ? in.hi[0] : in.lo[0], y = j ? in.hi[1] : in.lo[1], z = k ? in.hi[2] : in.lo[2];
+            double t[3] = {x, y, z};
+            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x + sn * z; t[2] = -sn * x + co * z; }
+            else if (op.kind == ZR_OP_ROTATE_X) { t[1] = co * y - sn * z; t[2] = sn * y + co * z; }
+            else { t[0] = co * x - sn * y; t[1] = sn * x + co * y; }
+            for (int q = 0; q < 3; q++) { b.lo[q] = std::fmin(b.lo[q], t[q]); b.hi[q] = std::fmax(b.hi[q], t[q]); }
+        }
+        return b;
+    }
+};
+
+inline float f_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return std::nextafterf(f, -std::numeric_limits<float>::infinity());
+}
+inline float f_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return std::nextafterf(f, std::numeric_limits<float>::infinity());
+}
+
+int validate(const zr_scene& s, const std::vector<zr_object>& objs) {
+    const size_t nm = s.materials.size(), nt = s.textures.size();
+    auto mat_ok = [&](uint32_t m) { return m == 0xFFFFFFFFu || m < nm; };
+    for (uint32_t m : s.sphere_mat) if (!mat_ok(m)) return fail(ZR_E_INVALID, "sphere material id %u out of range", m);
+    for (uint32_t m : s.tri_mat) if (!mat_ok(m)) return fail(ZR_E_INVALID, "triangle material id %u out of range", m);
+    for (uint32_t m : s.cube_mat) if (!mat_ok(m)) return fail(ZR_E_INVALID, "cube material id %u out of range", m);
+    auto chain_ok = [&](uint32_t cf, uint32_t cn) {
+        if (cn > ZR_MAX_CHAIN || (size_t)cf + cn > s.ops.size()) return false;
+        for (uint32_t k = 0; k < cn; k++) {
+            const zr_xform_op& op = s.ops[cf + k];
+            if (op.kind > ZR_OP_MATERIAL) return false;
+            if (op.kind == ZR_OP_MATERIAL && !mat_ok(op.mat)) return false;
+        }
+        return true;
+    };
+    auto prim_ok = [&](uint32_t type, uint32_t idx) {
+        switch (type) {
+            case ZR_PRIM_SPHERE: return idx < s.sphere_mat.size();
+            case ZR_PRIM_TRIANGLE: return idx < s.tri_mat.size();
+            case ZR_PRIM_CUBE: return idx < s.cube_mat.size();
+            case ZR_PRIM_MEDIUM: return idx < s.media.size();
+            default: return false;
+        }
+    };
+    for (const zr_medium& m : s.media) {
+        if (m.boundary_type != ZR_PRIM_SPHERE && m.boundary_type != ZR_PRIM_CUBE) return fail(ZR_E_INVALID, "medium boundary must be a sphere or a cube");
+        if (!prim_ok(m.boundary_type, m.boundary_index) || !chain_ok(m.chain_first, m.chain_count) || !mat_ok(m.mat))
+            return fail(ZR_E_INVALID, "medium references out of range (or wrapper chain longer than %d)", ZR_MAX_CHAIN);
+    }
+    for (const zr_object& o : objs)
+        if (!prim_ok(o.type, o.index) || !chain_ok(o.chain_first, o.chain_count))
+            return fail(ZR_E_INVALID, "world-list entry references out of range (or wrapper chain longer than %d)", ZR_MAX_CHAIN);
+    for (const zr_material& m : s.materials) {
+        if (m.kind > ZR_MAT_ISOTROPIC) return fail(ZR_E_INVALID, "unknown material kind %u", m.kind);
+        if (m.kind != ZR_MAT_DIELECTRIC && m.tex >= nt) return fail(ZR_E_INVALID, "material texture id out of range");
+        if (m.bump_tex != ZR_NO_TEXTURE && m.bump_tex >= nt) return fail(ZR_E_INVALID, "material bump texture id out of range");
+    }
+    for (const zr_texture& t : s.textures) {
+        if (t.kind > ZR_TEX_IMAGE_F32) return fail(ZR_E_INVALID, "unknown texture kind %u", t.kind);
+        if (t.kind == ZR_TEX_CHECKER && (t.odd >= nt || t.even >= nt)) return fail(ZR_E_INVALID, "checker child texture out of range");
+        if (t.kind >= ZR_TEX_IMAGE_U8 && t.width && t.height) {
+            size_t bytes = (size_t)t.width * t.height * 3 * (t.kind == ZR_TEX_IMAGE_F32 ? 4 : 1);
+            if (t.texel_offset + bytes > s.texels.size()) return fail(ZR_E_INVALID, "image texture texels out of range");
+            if (t.kind == ZR_TEX_IMAGE_F32 && (t.texel_offset & 3)) return fail(ZR_E_INVALID, "float texels must be 4-byte aligned");
+        }
+    }
+    return ZR_OK;
+}
+
+// flattens the build tree into sibling-pair records and, leaf by leaf, the primitive arrays in leaf order
+struct Flattener {
+    const zr_scene& s;
+    const std::vector<zr_object>& objs;
+    const zr::BuildResult& br;
+    std::vector<zr::NodePair> pairs;
+    std::vector<double> spheres, tri_v, tri_n, cubes;
+    std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
+    std::vector<zr::DMedium> media;
+    std::vector<zr::DWrapped> wrapped;
+
+    uint32_t append_prim(uint32_t type, uint32_t idx) {
+        switch (type) {
+            case ZR_PRIM_SPHERE: {
+                const double* q = &s.spheres[(size_t)idx * 4];
+                spheres.insert(spheres.end(), {q[0], q[1], q[2], std::fmax(0, q[3])});  // sphere.hpp:9
+                sphere_mat.push_back(s.sphere_mat[idx]);
+                return (uint32_t)sphere_mat.size() - 1;
+            }
+            case ZR_PRIM_TRIANGLE: {
+                tri_v.insert(tri_v.end(), &s.tri_v[(size_t)idx * 9], &s.tri_v[(size_t)idx * 9] + 9);
+                tri_n.insert(tri_n.end(), &s.tri_n[(size_t)idx * 9], &s.tri_n[(size_t)idx * 9] + 9);
+                tri_mat.push_back(s.tri_mat[idx]);
+                return (uint32_t)tri_mat.size() - 1;
+            }
+            case ZR_PRIM_CUBE: {
+                cubes.insert(cubes.end(), &s.cubes[(size_t)idx * 12], &s.cubes[(size_t)idx * 12] + 6);
+                cube_mat.push_back(s.cube_mat[idx]);
+                return (uint32_t)cube_mat.size() - 1;
+            }
+            default: {
+                const zr_medium& m = s.media[idx];
+                zr::DMedium d{};
+                d.btype = m.boundary_type; d.chain_first = m.chain_first; d.chain_count = m.chain_count;
+                d.mat = m.mat; d.id = idx; d.neg_inv_density = m.neg_inv_density;
+                d.bindex = append_prim(m.boundary_type, m.boundary_index);
+                media.push_back(d);
+                return (uint32_t)media.size() - 1;
+            }
+        }
+    }
+    // returns the first device index of the leaf's objects within its kind's array
+    uint32_t append_leaf(const zr::BuildNode& n) {
+        uint32_t first = 0;
+        for (uint32_t k = 0; k < n.count; k++) {
+            const zr_object& o = objs[br.order[n.first + k]];
+            uint32_t di;
+            if (n.kind == ZR_KIND_WRAPPED) {
+                // reserve the slot order: inner primitives first would break contiguity of wrapped[] — it does not,
+                // wrapped[] only grows here
+                zr::DWrapped w{};
+                w.type = o.type; w.chain_first = o.chain_first; w.chain_count = o.chain_count;
+                w.index = append_prim(o.type, o.index);
+                wrapped.push_back(w);
+                di = (uint32_t)wrapped.size() - 1;
+            } else {
+                di = append_prim(o.type, o.index);
+            }
+            if (k == 0) first = di;
+        }
+        return first;
+    }
+    void set_child(uint32_t pair, int slot, int32_t node_id) {
+        const zr::BuildNode& n = br.nodes[node_id];
+        for (int k = 0; k < 3; k++) { pairs[pair].lo[slot][k] = f_down(n.box.lo[k]); pairs[pair].hi[slot][k] = f_up(n.box.hi[k]); }
+        if (n.count) {
+            uint32_t first = append_leaf(n);
+            pairs[pair].child[slot] = first;
+            pairs[pair].meta[slot] = ((n.kind + 1u) << 16) | n.count;
+        } else {
+            uint32_t c = emit_pair(node_id);
+            pairs[pair].child[slot] = c;
+            pairs[pair].meta[slot] = 0;
+        }
+    }
+    uint32_t emit_pair(int32_t node_id) {
+        uint32_t p = (uint32_t)pairs.size();
+        pairs.push_back(zr::NodePair{});
+        const zr::BuildNode n = br.nodes[node_id];
+        set_child(p, 0, n.left);
+        set_child(p, 1, n.right);
+        return p;
+    }
+    void empty_child(uint32_t pair, int slot) {
+        for (int k = 0; k < 3; k++) { pairs[pair].lo[slot][k] = 0.f; pairs[pair].hi[slot][k] = 0.f; }
+        pairs[pair].child[slot] = 0;
+        pairs[pair].meta[slot] = (1u << 16) | 0u;  // leaf with zero primitives
+    }
+    void run() {
+        if (br.nodes.empty()) { pairs.push_back(zr::NodePair{}); empty_child(0, 0); empty_child(0, 1); return; }
+        if (br.nodes[0].count) {  // the whole world fits one leaf
+            pairs.push_back(zr::NodePair{});
+            set_child(0, 0, 0);
+            empty_child(0, 1);
+            return;
+        }
+        emit_pair(0);
+    }
+};
+
+double env_double(const char* name, double dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atof(v) : dflt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zr_abi_version(void) { return ZR_ABI_VERSION; }
+const char* zr_last_error(void) { return g_err.c_str(); }
+
+zr_ctx* zr_create(int device_ordinal) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(ZR_E_DEVICE, "no HIP device available (%s): this library has no CPU path", hipGetErrorString(e)); return nullptr; }
+    if (device_ordinal < 0 || device_ordinal >= n) { fail(ZR_E_INVALID, "device ordinal %d out of range (0..%d)", device_ordinal, n - 1); return nullptr; }
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) { fail(ZR_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+    zr_ctx* c = new zr_ctx();
+    c->device = device_ordinal;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
+    }
+    if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
+    return c;
+}
+
+void zr_destroy(zr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    c->d_ctr.release(); c->d_out.release(); c->d_tiles.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+zr_scene* zr_scene_create(zr_ctx* c) {
+    if (!c) { fail(ZR_E_INVALID, "null context"); return nullptr; }
+    zr_scene* s = new zr_scene();
+    s->ctx = c;
+    return s;
+}
+void zr_scene_destroy(zr_scene* s) {
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    delete s;
+}
+
+#define CHECK_SCENE(s) do { if (!(s)) return fail(ZR_E_INVALID, "null scene"); (s)->committed = false; } while (0)
+
+int zr_scene_set_spheres(zr_scene* s, const double* p, const uint32_t* mat, size_t n) {
+    CHECK_SCENE(s);
+    if (n && (!p || !mat)) return fail(ZR_E_INVALID, "null sphere arrays");
+    s->spheres.assign(p, p + n * 4); s->sphere_mat.assign(mat, mat + n);
+    return ZR_OK;
+}
+int zr_scene_set_triangles(zr_scene* s, const double* v9, const double* n9, const uint32_t* mat, size_t n) {
+    CHECK_SCENE(s);
+    if (n && (!v9 || !n9 || !mat)) return fail(ZR_E_INVALID, "null triangle arrays");
+    s->tri_v.assign(v9, v9 + n * 9); s->tri_n.assign(n9, n9 + n * 9); s->tri_mat.assign(mat, mat + n);
+    return ZR_OK;
+}
+int zr_scene_set_cubes(zr_scene* s, const double* q, const uint32_t* mat, size_t n) {
+    CHECK_SCENE(s);
+    if (n && (!q || !mat)) return fail(ZR_E_INVALID, "null cube arrays");
+    s->cubes.assign(q, q + n * 12); s->cube_mat.assign(mat, mat + n);
+    return ZR_OK;
+}
+int zr_scene_set_media(zr_scene* s, const zr_medium* m, size_t n) {
+    CHECK_SCENE(s);
+    if (n && !m) return fail(ZR_E_INVALID, "null media array");
+    s->media.assign(m, m + n);
+    return ZR_OK;
+}
+int zr_scene_set_xform_ops(zr_scene* s, const zr_xform_op* o, size_t n) {
+    CHECK_SCENE(s);
+    if (n && !o) return fail(ZR_E_INVALID, "null op array");
+    s->ops.assign(o, o + n);
+    return ZR_OK;
+}
+int zr_scene_set_objects(zr_scene* s, const zr_object* o, size_t n) {
+    CHECK_SCENE(s);
+    if (n && !o) return fail(ZR_E_INVALID, "null object array");
+    s->objects.assign(o, o + n); s->objects_set = n > 0;
+    return ZR_OK;
+}
+int zr_scene_set_materials(zr_scene* s, const zr_material* m, size_t n) {
+    CHECK_SCENE(s);
+    if (n && !m) return fail(ZR_E_INVALID, "null material array");
+    s->materials.assign(m, m + n);
+    return ZR_OK;
+}
+int zr_scene_set_textures(zr_scene* s, const zr_texture* t, size_t n, const void* blob, size_t bytes) {
+    CHECK_SCENE(s);
+    if ((n && !t) || (bytes && !blob)) return fail(ZR_E_INVALID, "null texture arrays");
+    s->textures.assign(t, t + n);
+    s->texels.assign((const unsigned char*)blob, (const unsigned char*)blob + bytes);
+    return ZR_OK;
+}
+int zr_scene_set_all(zr_scene* s, const zr_scene_desc* d) {
+    CHECK_SCENE(s);
+    if (!d) return fail(ZR_E_INVALID, "null scene description");
+    int rc;
+    if ((rc = zr_scene_set_spheres(s, d->spheres, d->sphere_mat, d->n_spheres))) return rc;
+    if ((rc = zr_scene_set_triangles(s, d->tri_v, d->tri_n, d->tri_mat, d->n_tris))) return rc;
+    if ((rc = zr_scene_set_cubes(s, d->cubes, d->cube_mat, d->n_cubes))) return rc;
+    if ((rc = zr_scene_set_media(s, d->media, d->n_media))) return rc;
+    if ((rc = zr_scene_set_xform_ops(s, d->ops, d->n_ops))) return rc;
+    if ((rc = zr_scene_set_objects(s, d->objects, d->n_objects))) return rc;
+    if ((rc = zr_scene_set_materials(s, d->materials, d->n_materials))) return rc;
+    return zr_scene_set_textures(s, d->textures, d->n_textures, d->texels, d->texel_bytes);
+}
+
+int zr_scene_commit(zr_scene* s) {
+    if (!s) return fail(ZR_E_INVALID, "null scene");
+    s->committed = false;
+    HIP_OK(hipSetDevice(s->ctx->device));
+    // the world list
+    std::vector<zr_object> objs;
+    if (s->objects_set) objs = s->objects;
+    else {
+        std::vector<char> sb(s->sphere_mat.size(), 0), cb(s->cube_mat.size(), 0);
+        for (const zr_medium& m : s->media) {
+            if (m.boundary_type == ZR_PRIM_SPHERE && m.boundary_index < sb.size()) sb[m.boundary_index] = 1;
+            if (m.boundary_type == ZR_PRIM_CUBE && m.boundary_index < cb.size()) cb[m.boundary_index] = 1;
+        }
+        for (uint32_t k = 0; k < s->sphere_mat.size(); k++) if (!sb[k]) objs.push_back({ZR_PRIM_SPHERE, k, 0, 0});
+        for (uint32_t k = 0; k < s->tri_mat.size(); k++) objs.push_back({ZR_PRIM_TRIANGLE, k, 0, 0});
+        for (uint32_t k = 0; k < s->cube_mat.size(); k++) if (!cb[k]) objs.push_back({ZR_PRIM_CUBE, k, 0, 0});
+        for (uint32_t k = 0; k < s->media.size(); k++) objs.push_back({ZR_PRIM_MEDIUM, k, 0, 0});
+    }
+    int rc = validate(*s, objs);
+    if (rc) return rc;
+    if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
+
+    // boxes + kinds
+    Boxer boxer{*s};
+    std::vector<zr::BuildBox> boxes(objs.size());
+    std::vector<uint32_t> kinds(objs.size());
+    for (size_t k = 0; k < objs.size(); k++) {
+        const zr_object& o = objs[k];
+        boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
+        kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
+        for (int a = 0; a < 3; a++)
+            if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", k);
+    }
+    zr::BuildResult br;
+    double ck[8] = {env_double("ZR_BVH_COST_SPHERE", 1.0), env_double("ZR_BVH_COST_TRI", 1.5), env_double("ZR_BVH_COST_CUBE", 1.0),
+                    env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), 1, 1, 1};
+    int max_leaf = (int)env_double("ZR_BVH_MAX_LEAF", 4);
+    zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br);
+    if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
+
+    Flattener fl{*s, objs, br};
+    fl.run();
+
+    if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
+    if ((rc = s->d_spheres.upload(fl.spheres))) return rc;
+    if ((rc = s->d_sphere_mat.upload(fl.sphere_mat))) return rc;
+    if ((rc = s->d_tri_v.upload(fl.tri_v))) return rc;
+    if ((rc = s->d_tri_n.upload(fl.tri_n))) return rc;
+    if ((rc = s->d_tri_mat.upload(fl.tri_mat))) return rc;
+    if ((rc = s->d_cubes.upload(fl.cubes))) return rc;
+    if ((rc = s->d_cube_mat.upload(fl.cube_mat))) return rc;
+    if ((rc = s->d_media.upload(fl.media))) return rc;
+    if ((rc = s->d_wrapped.upload(fl.wrapped))) return rc;
+    if ((rc = s->d_ops.upload(s->ops))) return rc;
+    if ((rc = s->d_mats.upload(s->materials))) return rc;
+    if ((rc = s->d_texs.upload(s->textures))) return rc;
+    if ((rc = s->d_texels.upload(s->texels))) return rc;
+
+    zr::DScene& d = s->ds;
+    d.nodes = s->d_nodes.p;
+    d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
+    d.tri_v = s->d_tri_v.p; d.tri_n = s->d_tri_n.p; d.tri_mat = s->d_tri_mat.p;
+    d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
+    d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.ops = s->d_ops.p;
+    d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
+    d.n_mats = (uint32_t)s->materials.size();
+    d.root_meta = 0;
+    s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
+    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_n.size() + fl.cubes.size()) * 8 +
+                  (fl.sphere_mat.size() + fl.tri_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
+    s->committed = true;
+    return ZR_OK;
+}
+
+int zr_scene_stats(const zr_scene* s, uint64_t out[4]) {
+    if (!s || !s->committed) return fail(ZR_E_STATE, "scene not committed");
+    std::memcpy(out, s->stats, sizeof s->stats);
+    return ZR_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// camera::initialize, camera.hpp:358-399
+void make_camera(const zr_camera& c, zr::DCamera& d) {
+    int W = c.image_width < 1 ? 1 : c.image_width, H = c.image_height < 1 ? 1 : c.image_height;
+    double aspect = double(W) / H;
+    H3 center = h3(c.lookfrom), lookat = h3(c.lookat), vup = h3(c.vup);
+    double theta = c.vfov * kPi / 180.0;
+    double h = std::tan(theta / 2);
+    double vh = 2 * h * c.focus_dist;
+    double vw = vh * aspect;
+    H3 w = unit(center - lookat);
+    H3 u = unit(cross(vup, w));
+    H3 v = cross(w, u);
+    H3 vu = vw * u;
+    H3 vv = vh * -v;
+    H3 du = vu / W;
+    H3 dv = vv / H;
+    H3 ul = center - (c.focus_dist * w) - vu / 2 - vv / 2;
+    H3 p00 = ul + 0.5 * (du + dv);
+    double rad = c.focus_dist * std::tan((c.defocus_angle / 2) * kPi / 180.0);
+    st3(d.center, center); st3(d.pixel00, p00); st3(d.du, du); st3(d.dv, dv);
+    st3(d.disk_u, u * rad); st3(d.disk_v, v * rad);
+    d.W = W; d.H = H; d.spp = c.samples_per_pixel < 1 ? 1 : c.samples_per_pixel; d.max_depth = c.max_depth;
+    d.defocus = !(c.defocus_angle <= 0) ? 1 : 0;
+    d.pad_ = 0;
+}
+
+// ray-independent part of get_background_color, camera.hpp:832-834, 844-858, 874-895, 914-918
+void make_env(const zr_env& e, zr::DEnv& d) {
+    std::memset(&d, 0, sizeof d);
+    d.mode = e.mode; d.hdr_tex = e.hdr_texture; d.intensity = e.intensity;
+    H3 bg = h3(e.background_color) * e.intensity;
+    st3(d.solid, bg);
+    d.cy = std::cos(e.hdri_rotation); d.sy = std::sin(e.hdri_rotation);
+    d.cp = std::cos(e.hdri_tilt); d.sp = std::sin(e.hdri_tilt);
+    d.cr = std::cos(e.hdri_roll); d.sr = std::sin(e.hdri_roll);
+    H3 sun = unit(h3(e.sun_direction));
+    double sh = sun.y;
+    double ah = sh - 0.05;
+    double sky_exposure = clampd(ah * 8.0 + 1.4, 0.0, 1.0);
+    double day = clampd(ah * 10.0 + 1.1, 0.0, 1.0);
+    double sunset_i = clampd(1.0 - std::fabs(ah + 0.05) * 30.0, 0.0, 1.0);
+    double sunset = (ah > -0.1) ? sunset_i : 0.0;
+    if (sh < 0) sunset *= (sh * 10.0 + 1.0);
+    sunset = clampd(sunset, 0.0, 1.0);
+    H3 zen = H3{0.01, 0.03, 0.1} * (1.0 - day) + H3{0.2, 0.5, 1.0} * day;
+    H3 hor = H3{0.05, 0.02, 0.01} * (1.0 - day) + H3{0.6, 0.8, 1.0} * day;
+    hor = hor * (1.0 - sunset) + H3{1.0, 0.35, 0.1} * sunset;
+    st3(d.sun, sun); st3(d.horizon, hor); st3(d.zenith, zen);
+    d.sky_scale = e.intensity * 1.5; d.sky_exposure = sky_exposure;
+    d.sun_thr = 1.0 - (e.sun_size * 0.001);
+    d.sun_on = ah > -0.1 ? 1 : 0;
+    H3 scol = h3(e.sun_color) * (1.0 - sunset) + H3{1.0, 0.3, 0.1} * sunset;
+    double vis = clampd(sh * 5.0 + 1.0, 0.0, 1.0);
+    st3(d.sun_add, (scol * e.sun_intensity) * vis);
+}
+
+struct Plan {
+    int W, H, ts, tiles_x, tiles_y, x0, y0, x1, y1, lanes;
+    std::vector<int32_t> tiles;
+};
+
+int make_plan(const zr_camera& cam, const zr_region* region, Plan& p) {
+    p.W = cam.image_width < 1 ? 1 : cam.image_width;
+    p.H = cam.image_height < 1 ? 1 : cam.image_height;
+    p.ts = 32; int mod = 1, rem = 0;
+    p.x0 = 0; p.y0 = 0; p.x1 = p.W; p.y1 = p.H;
+    if (region) {
+        if (region->tile_size > 0) p.ts = region->tile_size;
+        if (region->tile_mod > 1) { mod = region->tile_mod; rem = region->tile_rem; }
+        if (region->w > 0 && region->h > 0) { p.x0 = region->x0; p.y0 = region->y0; p.x1 = region->x0 + region->w; p.y1 = region->y0 + region->h; }
+    }
+    if (p.x0 < 0 || p.y0 < 0 || p.x1 > p.W || p.y1 > p.H || rem < 0 || rem >= mod || p.ts > 1024)
+        return fail(ZR_E_INVALID, "region outside the %dx%d frame or bad tile parameters", p.W, p.H);
+    p.tiles_x = (p.W + p.ts - 1) / p.ts; p.tiles_y = (p.H + p.ts - 1) / p.ts;
+    p.tiles.clear();
+    for (int ty = p.y0 / p.ts; ty <= (p.y1 - 1) / p.ts; ty++)
+        for (int tx = p.x0 / p.ts; tx <= (p.x1 - 1) / p.ts; tx++) {
+            int t = ty * p.tiles_x + tx;
+            if (t % mod == rem) p.tiles.push_back(t);
+        }
+    int spp = cam.samples_per_pixel < 1 ? 1 : cam.samples_per_pixel;
+    p.lanes = 64; while (p.lanes > spp) p.lanes >>= 1;
+    return ZR_OK;
+}
+
+int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const Plan& plan, int count,
+                   double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done) {
+    zr::DCamera dc; make_camera(*cam, dc);
+    zr::DEnv de; make_env(*env, de);
+    if (de.mode > ZR_ENV_SOLID_COLOR) return fail(ZR_E_INVALID, "unknown environment mode %u", de.mode);
+    if (de.mode == ZR_ENV_HDR_MAP && de.hdr_tex != ZR_NO_TEXTURE) {
+        if (de.hdr_tex >= s->textures.size()) return fail(ZR_E_INVALID, "environment texture id out of range");
+    }
+    std::vector<int32_t> tiles = plan.tiles;
+    int rc = c->d_tiles.upload(tiles);
+    if (rc) return rc;
+    if (count) HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", 1024));
+    size_t n_batches = (tiles.size() + batch - 1) / batch;
+    while (c->ev.size() < 2 * n_batches) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); c->ev.push_back(e); }
+    c->ev_used = 0; c->last_stream = stream; c->last_counted = count != 0; c->times_resolved = false; c->last_ms.clear();
+    for (size_t b = 0; b < n_batches; b++) {
+        if (keep_going && *keep_going == 0) {
+            HIP_OK(hipStreamSynchronize(stream));
+            return fail(ZR_E_CANCELLED, "render cancelled after %zu of %zu batches", b, n_batches);
+        }
+        zr::WorkDesc wd;
+        wd.tiles = c->d_tiles.p + b * batch;
+        wd.n_tiles = (int32_t)std::min<size_t>(batch, tiles.size() - b * batch);
+        wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
+        wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
+        wd.lanes_per_pixel = plan.lanes;
+        HIP_OK(hipEventRecord(c->ev[2 * b], stream));
+        HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
+        HIP_OK(hipEventRecord(c->ev[2 * b + 1], stream));
+        c->ev_used = 2 * (b + 1);
+        if (keep_going || rows_done) {
+            // progress / cancellation need the batch to have finished (camera.hpp:441,548-552)
+            HIP_OK(hipStreamSynchronize(stream));
+            if (rows_done) {
+                int last_tile = tiles[std::min(tiles.size(), (b + 1) * (size_t)batch) - 1];
+                int rows = std::min(plan.H, (last_tile / plan.tiles_x) * plan.ts);
+                if (rows > *rows_done) *rows_done = rows;
+            }
+        }
+    }
+    return ZR_OK;
+}
+
+int resolve_times(zr_ctx* c) {
+    if (c->times_resolved) return ZR_OK;
+    if (c->last_stream || c->ev_used) HIP_OK(hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+    c->last_ms.clear();
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]));
+        c->last_ms.push_back(ms);
+    }
+    c->times_resolved = true;
+    return ZR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zr_render_device(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const zr_region* region,
+                     int collect_counters, void* d_out_rgb, void* hip_stream) {
+    if (!c || !s || !cam || !env || !d_out_rgb) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_render");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    HIP_OK(hipSetDevice(c->device));
+    Plan plan;
+    int rc = make_plan(*cam, region, plan);
+    if (rc) return rc;
+    // default stream requested: use the legacy null stream so that callers' stream-ordered work (torch) sees it
+    hipStream_t st = (hipStream_t)hip_stream;
+    return enqueue_render(c, s, cam, env, seed, plan, collect_counters, (double*)d_out_rgb, st, nullptr, nullptr);
+}
+
+int zr_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const zr_region* region,
+              int collect_counters, double* out_rgb, volatile const uint8_t* keep_going, volatile int* rows_done) {
+    if (!c || !s || !cam || !env || !out_rgb) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_render");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    HIP_OK(hipSetDevice(c->device));
+    Plan plan;
+    int rc = make_plan(*cam, region, plan);
+    if (rc) return rc;
+    const size_t npx = (size_t)plan.W * plan.H;
+    if ((rc = c->d_out.alloc(npx * 3))) return rc;
+    HIP_OK(hipMemsetAsync(c->d_out.p, 0, npx * 3 * sizeof(double), c->stream));
+    if (rows_done) *rows_done = 0;
+    int rrc = enqueue_render(c, s, cam, env, seed, plan, collect_counters, c->d_out.p, c->stream, keep_going, rows_done);
+    if (rrc != ZR_OK && rrc != ZR_E_CANCELLED) return rrc;
+    std::string cancel_msg = g_err;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<double> frame(npx * 3);
+    HIP_OK(hipMemcpy(frame.data(), c->d_out.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int32_t t : plan.tiles) {
+        int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+        int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+        for (int y = ya; y < yb; y++)
+            if (xb > xa) std::memcpy(out_rgb + ((size_t)y * plan.W + xa) * 3, frame.data() + ((size_t)y * plan.W + xa) * 3, (size_t)(xb - xa) * 3 * sizeof(double));
+    }
+    if (rrc == ZR_E_CANCELLED) { g_err = cancel_msg; return rrc; }
+    if (rows_done) *rows_done = plan.H;  // camera.hpp:576-578
+    return ZR_OK;
+}
+
+int zr_get_counters(zr_ctx* c, zr_counters* out) {
+    if (!c || !out) return fail(ZR_E_INVALID, "null argument");
+    HIP_OK(hipSetDevice(c->device));
+    int rc = resolve_times(c);
+    if (rc) return rc;
+    std::memset(out, 0, sizeof *out);
+    for (float ms : c->last_ms) out->kernel_ms += ms;
+    if (c->last_counted) {
+        unsigned long long h[16];
+        HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
+        out->primary_samples = h[0]; out->segments = h[1]; out->nodes_tested = h[2]; out->spheres_tested = h[3];
+        out->triangles_tested = h[4]; out->cubes_tested = h[5]; out->media_tested = h[6]; out->hits = h[7]; out->rng_draws = h[8];
+    }
+    return ZR_OK;
+}
+
+int zr_get_kernel_times(zr_ctx* c, float* ms, int cap) {
+    if (!c) return fail(ZR_E_INVALID, "null argument");
+    HIP_OK(hipSetDevice(c->device));
+    int rc = resolve_times(c);
+    if (rc) return rc;
+    int n = (int)std::min<size_t>(c->last_ms.size(), (size_t)std::max(cap, 0));
+    for (int k = 0; k < n; k++) ms[k] = c->last_ms[c->last_ms.size() - n + k];
+    return (int)c->last_ms.size();
+}
+
+int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
+             uint32_t bounce, zr_hit* out) {
+    if (!c || !s || (n && (!rays6 || !out))) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_trace");
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<double> d_rays; DevBuf<zr_hit> d_hits;
+    std::vector<double> r(rays6, rays6 + n * 6);
+    int rc;
+    if ((rc = d_rays.upload(r))) return rc;
+    if ((rc = d_hits.alloc(n))) return rc;
+    HIP_OK(zr::launch_trace(s->ds, d_rays.p, n, tmin, tmax, seed, pixel, bounce, d_hits.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (n) HIP_OK(hipMemcpy(out, d_hits.p, n * sizeof(zr_hit), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// zr_kernels.hip — render kernels for gfx950 (MI355X).  Replaces the reference's std::thread row-block
+// sample loop (camera.hpp:404-579) and everything it calls per sample.
+//
+// Kernel `render_pixels` (variant 0, "pixel-group megakernel"):
+//   * a group of L = min(64, 2^floor(log2 spp)) lanes owns one pixel; with spp >= 64 that is one whole
+//     wave64 per pixel, so the 64 primary rays of a wave start coherent (same pixel footprint);
+//   * every lane runs the complete path of its samples (s = lane, lane + L, ...) in registers;
+//   * the BVH walk keeps its per-lane stack in LDS, laid out [depth][thread] so that the 64 lanes of a
+//     wave hit 64 consecutive banks (no conflicts);
+//   * radiance is summed per lane and reduced across the group with wave shuffles (the "warp-reduced
+//     HDR accumulator"); one lane stores the pixel mean — no atomics, so the image is bit-reproducible.
+#include "zr_device.h"
+#include "zr_launch.h"
+
+namespace zr {
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// radiance of one primary sample: camera.hpp:455-461,520 + ray_color_from_hit 989-1004 + ray_color 928-986
+template <bool COUNT>
+__device__ inline V3 sample_radiance(const DScene& sc, const DCamera& cam, const DEnv& env, int i, int j, Rng& g, uint32_t* stack,
+                                     int stride, Counters& ctr, uint32_t& segments, uint32_t& hits) {
+    Ray r = camera_ray(cam, i, j, g);
+    double t; uint32_t kind, idx;
+    segments++;
+    bool h = closest_hit<COUNT>(sc, r, 0.001, g, stack, stride, t, kind, idx, ctr);
+    g.bounce++;
+    if (!h) return background(sc, env, r.d);
+    hits++;
+    Rec rec;
+    object_rec(sc, kind, idx, r, t, rec);
+    V3 L0 = emitted(sc, rec);
+    V3 att0; Ray cur;
+    if (!scatter(sc, r, rec, att0, cur, g)) return L0;
+    // ray_color(scattered, depth - 1): its own L / beta start from (0, 1); loop index i restarts at 0
+    V3 L = mk(0, 0, 0), beta = mk(1, 1, 1);
+    const int depth = cam.max_depth - 1;
+    bool missed = false;
+    for (int b = 0; b < depth; b++) {
+        segments++;
+        h = closest_hit<COUNT>(sc, cur, 0.001, g, stack, stride, t, kind, idx, ctr);
+        g.bounce++;
+        if (!h) { missed = true; break; }
+        hits++;
+        object_rec(sc, kind, idx, cur, t, rec);
+        L = L + beta * emitted(sc, rec);
+        V3 att; Ray out;
+        if (!scatter(sc, cur, rec, att, out, g)) break;
+        beta = beta * att;
+        cur = out;
+        if (b > 10) {
+            if (len(beta) < 0.0001) break;
+            double p = fmax(fmax(beta.x, beta.y), beta.z);
+            p = clampd(p, 0.05, 0.95);
+            if (g.next() > p) break;
+            beta = beta * (1 / p);
+        }
+    }
+    if (missed) L = L + beta * background(sc, env, cur.d);
+    return L0 + att0 * L;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(ZR_BLOCK) void render_pixels(DScene sc, DCamera cam, DEnv env, uint64_t seed, WorkDesc wd, double* __restrict__ out,
+                                                           unsigned long long* __restrict__ gctr) {
+    __shared__ uint32_t lds_stack[ZR_STACK_DEPTH * ZR_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const int L = wd.lanes_per_pixel;
+    const int groups_per_block = ZR_BLOCK / L;
+    const int group = threadIdx.x / L, lane_in_group = threadIdx.x % L;
+    const long long q = (long long)blockIdx.x * groups_per_block + group;  // pixel slot in the tile enumeration
+    const int tpix = wd.tile_size * wd.tile_size;
+    bool active = q < (long long)wd.n_tiles * tpix;
+    int px = 0, py = 0;
+    if (active) {
+        int tile = wd.tiles[q / tpix];
+        int local = (int)(q % tpix);
+        px = (tile % wd.tiles_x) * wd.tile_size + local % wd.tile_size;
+        py = (tile / wd.tiles_x) * wd.tile_size + local / wd.tile_size;
+        active = px >= wd.x0 && px < wd.x1 && py >= wd.y0 && py < wd.y1;
+    }
+    V3 sum = mk(0, 0, 0);
+    Counters ctr = {0, 0, 0, 0, 0};
+    uint32_t segments = 0, hits = 0, nsamp = 0;
+    uint64_t draws = 0;
+    if (active) {
+        const uint64_t pixel = (uint64_t)py * (uint64_t)cam.W + (uint64_t)px;
+        for (int s = lane_in_group; s < cam.spp; s += L) {
+            Rng g; g.key = zr_stream_key(seed, pixel, (uint64_t)s); g.k = 0; g.bounce = 0;
+            V3 c = sample_radiance<COUNT>(sc, cam, env, px, py, g, stack, ZR_BLOCK, ctr, segments, hits);
+            sum = sum + c;
+            nsamp++;
+            if (COUNT) draws += g.k;
+        }
+    }
+    // group reduction (L is a power of two <= 64 and groups are wave-aligned)
+    for (int m = 1; m < L; m <<= 1) {
+        sum.x += shfl_xor_f64(sum.x, m);
+        sum.y += shfl_xor_f64(sum.y, m);
+        sum.z += shfl_xor_f64(sum.z, m);
+    }
+    if (active && lane_in_group == 0) {
+        const double scale = 1.0 / cam.spp;  // camera.hpp:437,531
+        double* o = out + ((size_t)py * cam.W + px) * 3;
+        o[0] = sum.x * scale; o[1] = sum.y * scale; o[2] = sum.z * scale;
+    }
+    if (COUNT && active) {
+        atomicAdd(&gctr[0], (unsigned long long)nsamp);
+        atomicAdd(&gctr[1], (unsigned long long)segments);
+        atomicAdd(&gctr[2], (unsigned long long)ctr.nodes);
+        atomicAdd(&gctr[3], (unsigned long long)ctr.sph);
+        atomicAdd(&gctr[4], (unsigned long long)ctr.tri);
+        atomicAdd(&gctr[5], (unsigned long long)ctr.cube);
+        atomicAdd(&gctr[6], (unsigned long long)ctr.med);
+        atomicAdd(&gctr[7], (unsigned long long)hits);
+        atomicAdd(&gctr[8], (unsigned long long)draws);
+    }
+}
+
+// known-answer kernel: world.hit(r, interval(tmin, tmax), rec) for a batch of rays, one ray per thread
+__global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* __restrict__ rays, size_t n, double tmin, double tmax,
+                                                        uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* __restrict__ out) {
+    __shared__ uint32_t lds_stack[ZR_STACK_DEPTH * ZR_BLOCK];
+    size_t k = (size_t)blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    Ray r; r.o = ld3(rays + k * 6); r.d = ld3(rays + k * 6 + 3);
+    Rng g; g.key = zr_stream_key(seed, pixel, k); g.k = 0; g.bounce = bounce;
+    Counters ctr = {0, 0, 0, 0, 0};
+    double t; uint32_t kind, idx;
+    bool h = closest_hit<false>(sc, r, tmin, g, lds_stack + threadIdx.x, ZR_BLOCK, t, kind, idx, ctr);
+    zr_hit o;
+    if (h && t < tmax) {
+        Rec rec;
+        object_rec(sc, kind, idx, r, t, rec);
+        o.p[0] = rec.p.x; o.p[1] = rec.p.y; o.p[2] = rec.p.z;
+        o.normal[0] = rec.n.x; o.normal[1] = rec.n.y; o.normal[2] = rec.n.z;
+        o.tangent[0] = rec.tan.x; o.tangent[1] = rec.tan.y; o.tangent[2] = rec.tan.z;
+        o.bitangent[0] = rec.bit.x; o.bitangent[1] = rec.bit.y; o.bitangent[2] = rec.bit.z;
+        o.t = rec.t; o.u = rec.u; o.v = rec.v; o.mat = rec.mat; o.front_face = rec.front ? 1u : 0u;
+    } else {
+        for (int c = 0; c < 3; c++) { o.p[c] = 0; o.normal[c] = 0; o.tangent[c] = 0; o.bitangent[c] = 0; }
+        o.t = 0; o.u = 0; o.v = 0; o.mat = 0xFFFFFFFFu; o.front_face = 0;
+    }
+    out[k] = o;
+}
+
+// ---- launch wrappers (called from zr_host.cpp) -------------------------------------------------------
+hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
+                         unsigned long long* gctr, bool count, hipStream_t stream) {
+    const int groups_per_block = ZR_BLOCK / wd.lanes_per_pixel;
+    const long long pixels = (long long)wd.n_tiles * wd.tile_size * wd.tile_size;
+    const long long blocks = (pixels + groups_per_block - 1) / groups_per_block;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block(ZR_BLOCK);
+    if (count) hipLaunchKernelGGL(render_pixels<true>, grid, block, 0, stream, sc, cam, env, seed, wd, out, gctr);
+    else hipLaunchKernelGGL(render_pixels<false>, grid, block, 0, stream, sc, cam, env, seed, wd, out, gctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
+                        uint32_t bounce, zr_hit* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned)((n + ZR_BLOCK - 1) / ZR_BLOCK)), block(ZR_BLOCK);
+    hipLaunchKernelGGL(trace_rays, grid, block, 0, stream, sc, rays, n, tmin, tmax, seed, pixel, bounce, out);
+    return hipGetLastError();
+}
+
+}  // namespace zr

@@ -1,0 +1,29 @@
+// zr_launch.h — host-visible launch interface of zr_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/zr_capi.h"
+
+#define ZR_BLOCK 256
+
+namespace zr {
+
+struct DScene;
+struct DCamera;
+struct DEnv;
+
+// which pixels one launch covers: the tiles `tiles[0..n_tiles)` (row-major tile ids), clipped to the
+// rectangle [x0,x1) x [y0,y1)
+struct WorkDesc {
+    const int32_t* tiles;
+    int32_t n_tiles, tile_size, tiles_x;
+    int32_t x0, y0, x1, y1;
+    int32_t lanes_per_pixel;
+};
+
+hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
+                         unsigned long long* gctr, bool count, hipStream_t stream);
+hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
+                        uint32_t bounce, zr_hit* out, hipStream_t stream);
+
+}  // namespace zr

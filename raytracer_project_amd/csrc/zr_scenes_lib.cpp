@@ -1,0 +1,74 @@
+// zr_scenes_lib.cpp — libzr_scenes.so: the BASELINE.json scenes (scenes/zr_scenes.inc, the very file the
+// oracle harness compiles against the genuine reference headers) compiled against the drop-in API
+// (include/zenith/zenith.hpp).  Exposes (a) the flattened arrays, so that Python hosts (bench.py, tests)
+// can feed them to the C ABI, and (b) a render through the drop-in's camera::render(world, env, post, flag),
+// the same call the reference's main.cpp:1520-1521 makes.
+#include <unistd.h>
+
+#include "../../include/zenith/zenith.hpp"
+
+static void zr_hook_seed_scene(uint64_t seed, uint64_t stream) { zenith::seed_rng(seed, ZR_SCENE_PIXEL, stream); }
+static shared_ptr<hittable> zr_hook_medium(shared_ptr<hittable> m) { return m; }  // media ids = flatten order
+
+#include "../../scenes/zr_scenes.inc"
+#include "../../scenes/zr_scenes_mix.inc"
+
+namespace {
+struct handle {
+    zr_demo_scene s;
+    zenith::flat_scene fs;
+    zr_scene_desc desc{};
+    zr_env env{};
+    std::string warnings;
+};
+}  // namespace
+
+extern "C" {
+
+void* zrs_build(const char* name, int a0, int a1, int a2, int a3) {
+    handle* h = new handle();
+    bool ok = zr_build_scene(name, h->s, a0, a1, a2, a3) || zr_build_scene_mix(name, h->s);
+    if (!ok) { delete h; return nullptr; }
+    zenith::scene_builder b(h->fs);
+    h->s.world.flatten(b);
+    h->env = zenith::to_zr_env(h->s.env, b);
+    h->desc = h->fs.desc();
+    for (const auto& w : h->fs.warnings) { h->warnings += w; h->warnings += "\n"; }
+    for (const auto& f : h->s.temp_files) ::unlink(f.c_str());
+    h->s.temp_files.clear();
+    return h;
+}
+void zrs_free(void* p) { delete (handle*)p; }
+const zr_scene_desc* zrs_desc(void* p) { return &((handle*)p)->desc; }
+const zr_camera* zrs_camera(void* p) { return &((handle*)p)->s.cam; }
+const zr_env* zrs_env(void* p) { return &((handle*)p)->env; }
+uint64_t zrs_seed(void* p) { return ((handle*)p)->s.seed; }
+const char* zrs_warnings(void* p) { return ((handle*)p)->warnings.c_str(); }
+
+// Renders through the drop-in C++ API exactly as the reference's caller does.  out = W*H*3 doubles.
+// spp/width/height <= 0 keep the scene's values.  Returns 0, or -1 if the accumulator stayed empty.
+int zrs_render_dropin(void* p, int width, int height, int spp, int device, double* out, zr_counters* ctr) {
+    handle* h = (handle*)p;
+    camera cam;
+    const zr_camera& c = h->s.cam;
+    cam.image_width = width > 0 ? width : c.image_width;
+    cam.image_height = height > 0 ? height : c.image_height;
+    cam.samples_per_pixel = spp > 0 ? spp : c.samples_per_pixel;
+    cam.max_depth = c.max_depth; cam.vfov = c.vfov;
+    cam.lookfrom = point3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
+    cam.lookat = point3(c.lookat[0], c.lookat[1], c.lookat[2]);
+    cam.vup = vec3(c.vup[0], c.vup[1], c.vup[2]);
+    cam.defocus_angle = c.defocus_angle; cam.focus_dist = c.focus_dist;
+    cam.seed = h->s.seed; cam.device = device;
+    cam.reset_accumulator();
+    post_processor post;
+    std::atomic<bool> flag{true};
+    auto bvh_world = make_shared<bvh_node>(h->s.world);  // main.cpp:204
+    cam.render(*bvh_world, h->s.env, post, flag);
+    if (cam.lines_rendered.load() != cam.image_height) return -1;
+    std::memcpy(out, cam.render_accumulator.data(), cam.render_accumulator.size() * sizeof(color));
+    if (ctr) *ctr = cam.last_counters;
+    return 0;
+}
+
+}  // extern "C"
