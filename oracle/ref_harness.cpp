@@ -333,7 +333,7 @@ static int usage() {
                  "usage:\n"
                  "  zenith_ref tile   <scene> <x0> <y0> <w> <h> <spp|0> <threads> <out_prefix> [per_sample=0] [a0 a1 a2 a3]\n"
                  "  zenith_ref time   <scene> <xstep> <ystep> <spp|0> <threads> [a0 a1 a2 a3]\n"
-                 "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> [a0 a1 a2 a3]\n"
+                 "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> <clamp_lo> <clamp_hi> [a0 a1 a2 a3]\n"
                  "  zenith_ref texels <w> <h> <out.npy>\n");
     return 2;
 }
@@ -391,15 +391,16 @@ int main(int argc, char** argv) {
         // known answers of world.hit on random rays: rays aimed from a shell around the scene box
         // towards points inside it, plus rays starting inside.  Record = hit_record fields.
         built_scene b;
-        if (!build(b, argv[2], iarg(6, 0), iarg(7, 0), iarg(8, 0), iarg(9, 0))) return usage();
+        if (!build(b, argv[2], iarg(8, 0), iarg(9, 0), iarg(10, 0), iarg(11, 0))) return usage();
+        const double clo = argc > 6 ? std::atof(argv[6]) : -30.0, chi = argc > 7 ? std::atof(argv[7]) : 600.0;
         size_t n = (size_t)iarg(3, 1000);
         uint64_t seed = (uint64_t)iarg(4, 1);
         std::string out = argv[5];
         aabb box = b.bvh->bounding_box();
         auto clampf = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
         // keep the probe region finite for scenes with a huge ground sphere
-        double lo[3] = {clampf(box.x.min, -30, 600), clampf(box.y.min, -30, 600), clampf(box.z.min, -30, 600)};
-        double hi[3] = {clampf(box.x.max, -30, 600), clampf(box.y.max, -30, 600), clampf(box.z.max, -30, 600)};
+        double lo[3] = {clampf(box.x.min, clo, chi), clampf(box.y.min, clo, chi), clampf(box.z.min, clo, chi)};
+        double hi[3] = {clampf(box.x.max, clo, chi), clampf(box.y.max, clo, chi), clampf(box.z.max, clo, chi)};
         std::vector<double> rays(n * 6), recs(n * 16);
         // map material pointers to first-seen ordinal so fixtures can compare material identity
         std::map<const material*, int> mat_id;

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the GENUINE reference arithmetic.
+
+Runs only in the build container: it executes oracle/_ref/zenith_ref, which oracle/Makefile compiles from
+the headers under /root/reference (never copied into this repo) plus oracle/ref_harness.cpp.  The fixtures
+are data only — inputs (scene name, region, seed, rays) and expected outputs (radiance, hit records,
+segment / RNG-draw counts).  Commit the .npz files together with this script.
+
+    python tests/golden/make_golden.py            # everything (cfg3_full takes ~1 min: 1M-triangle BVH)
+    python tests/golden/make_golden.py cfg1 mix0  # selected fixtures
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "zenith_ref")
+
+# name -> (scene, x0, y0, w, h, spp (0 = the config's own), per_sample, extra scene args)
+TILES = {
+    "cfg1_full": ("cfg1", 0, 0, 400, 225, 0, False, []),             # the whole plumbing config
+    "cfg1_tile": ("cfg1", 180, 100, 16, 16, 0, True, []),
+    "cfg2_tile": ("cfg2", 600, 300, 16, 16, 0, False, []),            # full 256 spp
+    "cfg2_tile_b": ("cfg2", 300, 420, 12, 12, 0, False, []),
+    "cfg3_small": ("cfg3", 900, 500, 24, 24, 64, False, [200, 20, 256, 128]),   # 8 000 triangles, 256x128 HDRI
+    "cfg3_full": ("cfg3", 944, 528, 16, 16, 0, False, []),            # 1 000 000 triangles, 4096x2048 HDRI, 512 spp
+    "cfg5_tile": ("cfg5", 250, 300, 8, 8, 0, False, []),              # 1024 spp, depth 50
+    "cfg5_tile_b": ("cfg5", 150, 450, 8, 8, 256, True, []),            # glass sphere region
+    "mix0_full": ("mix0", 0, 0, 96, 64, 0, False, []),
+    "mix1_full": ("mix1", 0, 0, 96, 64, 0, False, []),
+    "mix2_full": ("mix2", 0, 0, 96, 64, 0, False, []),
+    "mix0_tile": ("mix0", 30, 20, 16, 16, 0, True, []),
+}
+TRACES = {
+    # name -> (scene, rays, seed, probe-box clamp lo, hi, extra scene args)
+    "trace_mix0": ("mix0", 4096, 11, -6, 6, []),
+    "trace_cfg2": ("cfg2", 2048, 12, -12, 12, []),
+    "trace_cfg5": ("cfg5", 2048, 13, -30, 600, []),
+    "trace_cfg3_small": ("cfg3", 2048, 14, -4, 4, [200, 20, 256, 128]),
+}
+
+
+def run(*args):
+    p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/zenith_ref missing: run `make -C oracle ref` (needs /root/reference)")
+    want = set(sys.argv[1:])
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, (scene, x0, y0, w, h, spp, ps, extra) in TILES.items():
+            if want and name not in want and scene not in want:
+                continue
+            pre = os.path.join(tmp, name)
+            meta = run("tile", scene, x0, y0, w, h, spp, os.cpu_count() or 1, pre, 1 if ps else 0, *extra)
+            meta["scene_args"] = extra
+            arrays = {"mean": np.load(pre + "_mean.npy"), "meta": np.array(json.dumps(meta))}
+            if ps:
+                arrays["samples"] = np.load(pre + "_samples.npy")
+                arrays["counts"] = np.load(pre + "_counts.npy")
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
+            print(name, meta)
+        for name, (scene, n, seed, clo, chi, extra) in TRACES.items():
+            if want and name not in want and scene not in want:
+                continue
+            pre = os.path.join(tmp, name)
+            meta = run("trace", scene, n, seed, pre, clo, chi, *extra)
+            meta["scene_args"] = extra
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), rays=np.load(pre + "_rays.npy"),
+                                recs=np.load(pre + "_recs.npy"), meta=np.array(json.dumps(meta)))
+            print(name, meta)
+        if not want or "texels" in want:
+            out = os.path.join(tmp, "texels.npy")
+            subprocess.run([REF, "texels", "64", "32", out], check=True)
+            np.savez_compressed(os.path.join(HERE, "texels_hdr_64x32.npz"), texels=np.load(out))
+            print("texels 64x32")
+
+
+if __name__ == "__main__":
+    main()
