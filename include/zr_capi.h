@@ -245,7 +245,8 @@ int zr_render_device(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, 
                      void* d_out_rgb, void* hip_stream);
 /* counters + device time of the last render on this context (synchronises the context's stream) */
 int zr_get_counters(zr_ctx*, zr_counters*);
-/* device time (ms) of each of the last `cap` render-kernel launches, newest last; returns the count */
+/* drains the log of render-kernel launch durations (ms, measured with HIP events on the launch stream) recorded
+ * since the previous call: copies the newest min(cap, n) of them, oldest first, and returns n */
 int zr_get_kernel_times(zr_ctx*, float* ms, int cap);
 
 /* ---- known-answer entry: world.hit(r, interval(tmin,tmax), rec) for a batch of rays ---------- */

@@ -82,12 +82,15 @@ struct zr_ctx {
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
-    std::vector<hipEvent_t> ev;       // start/stop pairs of the last render's launches
-    size_t ev_used = 0;
+    // device timing of render-kernel launches: HIP events recorded on the stream the kernel is launched on
+    struct Pending { hipEvent_t a, b; uint64_t render_id; };
+    std::vector<hipEvent_t> pool;     // recycled events
+    std::vector<Pending> pending;     // launches not yet resolved to milliseconds
+    std::vector<float> log;           // resolved launch times since the last zr_get_kernel_times (oldest first)
+    uint64_t render_id = 0;
+    double last_render_ms = 0;        // sum over the launches of the most recent render call
     hipStream_t last_stream = nullptr;
     bool last_counted = false;
-    std::vector<float> last_ms;
-    bool times_resolved = true;
 };
 
 struct zr_scene {
@@ -361,7 +364,8 @@ void zr_destroy(zr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_ctr.release(); c->d_out.release(); c->d_tiles.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -613,6 +617,8 @@ int make_plan(const zr_camera& cam, const zr_region* region, Plan& p) {
     return ZR_OK;
 }
 
+int resolve_times(zr_ctx* c);
+
 int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const Plan& plan, int count,
                    double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done) {
     zr::DCamera dc; make_camera(*cam, dc);
@@ -625,10 +631,17 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
     if (count) HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
-    const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", 1024));
+    // one launch per frame unless the caller wants progress / cancellation, which need batch boundaries
+    const bool interactive = keep_going || rows_done;
+    const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", interactive ? 256 : (double)(1 << 30)));
     size_t n_batches = (tiles.size() + batch - 1) / batch;
-    while (c->ev.size() < 2 * n_batches) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); c->ev.push_back(e); }
-    c->ev_used = 0; c->last_stream = stream; c->last_counted = count != 0; c->times_resolved = false; c->last_ms.clear();
+    if (c->pending.size() > 4096) { int rr = resolve_times(c); if (rr) return rr; }
+    c->render_id++; c->last_stream = stream; c->last_counted = count != 0;
+    auto get_event = [&](hipEvent_t& e) -> int {
+        if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); return ZR_OK; }
+        HIP_OK(hipEventCreate(&e));
+        return ZR_OK;
+    };
     for (size_t b = 0; b < n_batches; b++) {
         if (keep_going && *keep_going == 0) {
             HIP_OK(hipStreamSynchronize(stream));
@@ -640,10 +653,12 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
         wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
         wd.lanes_per_pixel = plan.lanes;
-        HIP_OK(hipEventRecord(c->ev[2 * b], stream));
+        zr_ctx::Pending pe{}; pe.render_id = c->render_id;
+        if ((rc = get_event(pe.a)) || (rc = get_event(pe.b))) return rc;
+        HIP_OK(hipEventRecord(pe.a, stream));
         HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
-        HIP_OK(hipEventRecord(c->ev[2 * b + 1], stream));
-        c->ev_used = 2 * (b + 1);
+        HIP_OK(hipEventRecord(pe.b, stream));
+        c->pending.push_back(pe);
         if (keep_going || rows_done) {
             // progress / cancellation need the batch to have finished (camera.hpp:441,548-552)
             HIP_OK(hipStreamSynchronize(stream));
@@ -658,15 +673,18 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
 }
 
 int resolve_times(zr_ctx* c) {
-    if (c->times_resolved) return ZR_OK;
-    if (c->last_stream || c->ev_used) HIP_OK(hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
-    c->last_ms.clear();
-    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+    if (c->pending.empty()) return ZR_OK;
+    bool fresh = false;
+    for (auto& p : c->pending) {
+        HIP_OK(hipEventSynchronize(p.b));
         float ms = 0;
-        HIP_OK(hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]));
-        c->last_ms.push_back(ms);
+        HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
+        c->log.push_back(ms);
+        if (p.render_id == c->render_id) { if (!fresh) { c->last_render_ms = 0; fresh = true; } c->last_render_ms += ms; }
+        c->pool.push_back(p.a); c->pool.push_back(p.b);
     }
-    c->times_resolved = true;
+    c->pending.clear();
+    if (c->log.size() > (1u << 20)) c->log.erase(c->log.begin(), c->log.begin() + (c->log.size() - (1u << 20)));
     return ZR_OK;
 }
 
@@ -724,7 +742,7 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
     int rc = resolve_times(c);
     if (rc) return rc;
     std::memset(out, 0, sizeof *out);
-    for (float ms : c->last_ms) out->kernel_ms += ms;
+    out->kernel_ms = c->last_render_ms;
     if (c->last_counted) {
         unsigned long long h[16];
         HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
@@ -739,9 +757,11 @@ int zr_get_kernel_times(zr_ctx* c, float* ms, int cap) {
     HIP_OK(hipSetDevice(c->device));
     int rc = resolve_times(c);
     if (rc) return rc;
-    int n = (int)std::min<size_t>(c->last_ms.size(), (size_t)std::max(cap, 0));
-    for (int k = 0; k < n; k++) ms[k] = c->last_ms[c->last_ms.size() - n + k];
-    return (int)c->last_ms.size();
+    int total = (int)c->log.size();
+    int n = std::min(total, std::max(cap, 0));
+    for (int k = 0; k < n; k++) ms[k] = c->log[c->log.size() - n + k];
+    c->log.clear();
+    return total;
 }
 
 int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
