@@ -82,6 +82,10 @@ struct zr_ctx {
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
+    DevBuf<unsigned int> d_task;          // task-queue head of the persistent kernel
+    DevBuf<unsigned char> d_overflow;     // per-wave BVH stack spill slabs
+    int wf_blocks = 0;
+    int variant = 1;                      // 0 = pixel-group megakernel, 1 = wave-scheduler persistent kernel
     // device timing of render-kernel launches: HIP events recorded on the stream the kernel is launched on
     struct Pending { hipEvent_t a, b; uint64_t render_id; };
     std::vector<hipEvent_t> pool;     // recycled events
@@ -357,6 +361,13 @@ zr_ctx* zr_create(int device_ordinal) {
         fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
+    c->variant = (int)env_double("ZR_KERNEL", 1);
+    if (c->variant == 1) {
+        c->wf_blocks = zr::wavefront_max_blocks();
+        int over = (int)env_double("ZR_WF_BLOCKS", 0);
+        if (over > 0) c->wf_blocks = over;
+        if (c->d_task.alloc(1) != ZR_OK || c->d_overflow.alloc(zr::wavefront_overflow_bytes(c->wf_blocks)) != ZR_OK) { delete c; return nullptr; }
+    }
     return c;
 }
 
@@ -630,7 +641,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     std::vector<int32_t> tiles = plan.tiles;
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
-    if (count) HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
     // one launch per frame unless the caller wants progress / cancellation, which need batch boundaries
     const bool interactive = keep_going || rows_done;
     const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", interactive ? 256 : (double)(1 << 30)));
@@ -656,7 +667,10 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         zr_ctx::Pending pe{}; pe.render_id = c->render_id;
         if ((rc = get_event(pe.a)) || (rc = get_event(pe.b))) return rc;
         HIP_OK(hipEventRecord(pe.a, stream));
-        HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
+        if (c->variant == 1)
+            HIP_OK(zr::launch_render_wavefront(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, c->d_task.p, c->d_overflow.p, c->wf_blocks, stream));
+        else
+            HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
         HIP_OK(hipEventRecord(pe.b, stream));
         c->pending.push_back(pe);
         if (keep_going || rows_done) {
@@ -743,9 +757,10 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (rc) return rc;
     std::memset(out, 0, sizeof *out);
     out->kernel_ms = c->last_render_ms;
+    unsigned long long h[16];
+    HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
+    if (h[15] != 0) return fail(ZR_E_DEVICE, "render kernel hit its iteration cap on %llu task(s): results are incomplete", h[15]);
     if (c->last_counted) {
-        unsigned long long h[16];
-        HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
         out->primary_samples = h[0]; out->segments = h[1]; out->nodes_tested = h[2]; out->spheres_tested = h[3];
         out->triangles_tested = h[4]; out->cubes_tested = h[5]; out->media_tested = h[6]; out->hits = h[7]; out->rng_draws = h[8];
     }

@@ -23,6 +23,12 @@ struct WorkDesc {
 
 hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
                          unsigned long long* gctr, bool count, hipStream_t stream);
+// variant 1: persistent wave-scheduler kernel (zr_wavefront.hip)
+size_t wavefront_overflow_bytes(int blocks);
+int wavefront_max_blocks();
+hipError_t launch_render_wavefront(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
+                                   unsigned long long* gctr, bool count, unsigned int* task_counter, void* overflow, int max_blocks,
+                                   hipStream_t stream);
 hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
                         uint32_t bounce, zr_hit* out, hipStream_t stream);
 
