@@ -171,6 +171,9 @@ typedef struct zr_counters {
     uint64_t media_tested;
     uint64_t hits;           /* segments that found a surface / medium event */
     uint64_t rng_draws;      /* main-stream draws */
+    /* wave-scheduler statistics (kernel variant 1): executions of the NODE / LEAF / SHADE phase and the lanes
+     * that were ready at each execution (lanes / (64 * execs) = SIMT utilisation of the phase) */
+    uint64_t node_execs, node_lanes, leaf_execs, leaf_lanes, shade_execs, shade_lanes;
     double kernel_ms;        /* device time of the render kernels of the last call (hipEvents) */
 } zr_counters;
 

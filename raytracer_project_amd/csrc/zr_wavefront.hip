@@ -26,7 +26,7 @@
 namespace zr {
 
 #ifndef WF_MIN_WAVES
-#define WF_MIN_WAVES 4 /* waves per SIMD the register allocator must leave room for */
+#define WF_MIN_WAVES 2 /* waves per SIMD the register allocator must leave room for */
 #endif
 #define WF_LDS_STACK 16
 #define WF_OVERFLOW (ZR_STACK_DEPTH - WF_LDS_STACK)
@@ -56,6 +56,8 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
     // counters (COUNT build only)
     uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_cube = 0, c_med = 0, c_seg = 0, c_hits = 0, c_samp = 0;
     unsigned long long c_draws = 0;
+    // scheduler statistics (COUNT build only, wave-uniform): executions of each phase and lanes ready at each
+    unsigned long long s_exec[3] = {0, 0, 0}, s_lanes[3] = {0, 0, 0};
 
     for (;;) {
         unsigned int task = 0;
@@ -112,16 +114,21 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
         const unsigned long long iter_cap = (unsigned long long)total * 4096ull + (1ull << 22);
         unsigned long long iter = 0;
         for (; iter < iter_cap; iter++) {
+            const uint32_t lkind = (pa_meta >> 16) - 1u;  // kind of the pending leaf (valid in ST_LEAF)
             const int n1 = __popcll(__ballot(st == ST_NODE));
-            const int n2 = __popcll(__ballot(st == ST_LEAF));
+            const int n2t = __popcll(__ballot(st == ST_LEAF && lkind == ZR_PRIM_TRIANGLE));
+            const int n2s = __popcll(__ballot(st == ST_LEAF && lkind == ZR_PRIM_SPHERE));
+            const int n2g = __popcll(__ballot(st == ST_LEAF)) - n2t - n2s;  // cubes, media, wrapped objects
             const int n3 = __popcll(__ballot(st == ST_SHADE));
             const int n0 = __popcll(__ballot(st == ST_NEED));
             const bool work_left = next_q < total;
             const int n3e = n3 + (work_left ? n0 : 0);
+            const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);  // best leaf sub-phase
             if (n1 + n2 + n3e == 0) break;
 
             if (n1 >= n2 && n1 >= n3e) {
                 // ================= NODE phase: one sibling-pair record per lane =================
+                if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
                 if (st == ST_NODE) {
                     const NodePair* np = sc.nodes + cur;
                     const float4 q0 = reinterpret_cast<const float4*>(np)[0];
@@ -179,10 +186,12 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
                 }
             } else if (n2 >= n3e) {
                 // ================= LEAF phase: one primitive per lane, grouped by kind =================
-                const uint32_t kind = (pa_meta >> 16) - 1u;
+                // the leaf kind with the most waiting lanes runs; the other kinds keep waiting
+                const uint32_t kind = lkind;
                 const bool is_leaf = st == ST_LEAF;
-                const bool any_tri = __ballot(is_leaf && kind == ZR_PRIM_TRIANGLE) != 0ull;
-                const bool any_sph = __ballot(is_leaf && kind == ZR_PRIM_SPHERE) != 0ull;
+                const bool any_tri = n2t == n2;
+                const bool any_sph = !any_tri && n2s == n2;
+                if (COUNT) { s_exec[1]++; s_lanes[1] += n2; }
                 bool tested = false;
                 if (any_tri) {
                     if (is_leaf && kind == ZR_PRIM_TRIANGLE) {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
                         if (sphere_t(sc.spheres + (size_t)(pa_first + pend_i) * 4, ray, 0.001, tbest, t)) { tbest = t; kbest = kind; ibest = pa_first + pend_i; }
                         tested = true;
                     }
-                } else if (is_leaf) {
+                } else if (is_leaf && kind != ZR_PRIM_TRIANGLE && kind != ZR_PRIM_SPHERE) {
                     double t;
                     if (COUNT) {
                         uint32_t kk = kind;
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
                 }
             } else {
                 // ================= SHADE phase: finish segments, then regenerate =================
+                if (COUNT) { s_exec[2]++; s_lanes[2] += n3; }
                 if (st == ST_SHADE) {
                     g.bounce++;
                     bool ended = false;   // path ended: `contrib` is added to the pixel
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
         atomicAdd(&gctr[6], (unsigned long long)c_med);
         atomicAdd(&gctr[7], (unsigned long long)c_hits);
         atomicAdd(&gctr[8], c_draws);
+        if (lane == 0) for (int k = 0; k < 3; k++) { atomicAdd(&gctr[9 + 2 * k], s_exec[k]); atomicAdd(&gctr[10 + 2 * k], s_lanes[k]); }
     }
 }
 
