@@ -174,6 +174,8 @@ typedef struct zr_counters {
     /* wave-scheduler statistics (kernel variant 1): executions of the NODE / LEAF / SHADE phase and the lanes
      * that were ready at each execution (lanes / (64 * execs) = SIMT utilisation of the phase) */
     uint64_t node_execs, node_lanes, leaf_execs, leaf_lanes, shade_execs, shade_lanes;
+    uint64_t rounds;         /* kernel variant 2: EXTEND/SHADE rounds of the last render */
+    double extend_ms, shade_ms; /* kernel variant 2: device time of the EXTEND / SHADE launches of the last render */
     double kernel_ms;        /* device time of the render kernels of the last call (hipEvents) */
 } zr_counters;
 

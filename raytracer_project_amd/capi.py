@@ -72,7 +72,8 @@ class Counters(C.Structure):
                 ("spheres_tested", C.c_uint64), ("triangles_tested", C.c_uint64), ("cubes_tested", C.c_uint64),
                 ("media_tested", C.c_uint64), ("hits", C.c_uint64), ("rng_draws", C.c_uint64),
                 ("node_execs", C.c_uint64), ("node_lanes", C.c_uint64), ("leaf_execs", C.c_uint64), ("leaf_lanes", C.c_uint64),
-                ("shade_execs", C.c_uint64), ("shade_lanes", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("shade_execs", C.c_uint64), ("shade_lanes", C.c_uint64), ("rounds", C.c_uint64),
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

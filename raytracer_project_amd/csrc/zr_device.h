@@ -164,23 +164,32 @@ __device__ __forceinline__ bool sphere_t(const double* s, const Ray& r, double t
     return true;
 }
 
-// triangle.hpp:17-57.  contains(): inclusive.  Outputs what the record needs so it is not recomputed.
+// triangle.hpp:17-57, distance only.  Same decisions as the reference — degenerate (|N| < 1e-8), parallel
+// (|N̂·d| < 1e-8), contains(t) inclusive, the three edge tests N·((v_{k+1}-v_k) x (p-v_k)) >= 0 — evaluated in the
+// algebraically identical scaled-barycentric form, which needs no square root and a single division, and only
+// for lanes that are inside:
+//   with s = o - v0, q = d x e2, r = s x e1, det = e1·q = -(N·d):   N·C0 = |N|^2 v,  N·C2 = |N|^2 u,  N·C1 = |N|^2 (1-u-v)
+//   u = (s·q)/det,  v = (d·r)/det,  t = (e2·r)/det = N·(v0 - o) / (N·d)
+// The values differ from the reference's normalised-plane formula only in the last bits (~1e-15 relative).
 __device__ __forceinline__ bool triangle_t(const double* v, const Ray& r, double tmin, double tmax, double& t) {
     V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
-    V3 normal = cross(v1 - v0, v2 - v0);
-    double nl = len(normal);
-    if (nl < 1e-8) return false;
-    V3 un = vdiv(normal, nl);
-    double nd = dot(un, r.d);
-    if (fabs(nd) < 1e-8) return false;
-    double D = dot(un, v0);
-    double tt = (D - dot(un, r.o)) / nd;
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 n = cross(e1, e2);
+    double nn = len2(n);
+    if (nn < 1e-16) return false;                 // normal_length < 1e-8
+    V3 q = cross(r.d, e2);
+    double det = dot(e1, q);                      // = -(N·d)
+    if (det * det < 1e-16 * nn) return false;     // |N̂·d| < 1e-8
+    V3 s = r.o - v0;
+    double un = dot(s, q);
+    V3 rr = cross(s, e1);
+    double vn = dot(r.d, rr);
+    double sg = det < 0 ? -1.0 : 1.0;
+    double ad = det * sg;
+    un *= sg; vn *= sg;
+    if (un < 0 || vn < 0 || un + vn > ad) return false;
+    double tt = dot(e2, rr) / det;
     if (!(tmin <= tt && tt <= tmax)) return false;
-    V3 p = at(r, tt);
-    V3 C0 = cross(v1 - v0, p - v0);
-    V3 C1 = cross(v2 - v1, p - v1);
-    V3 C2 = cross(v0 - v2, p - v2);
-    if (dot(normal, C0) < 0 || dot(normal, C1) < 0 || dot(normal, C2) < 0) return false;
     t = tt;
     return true;
 }

@@ -85,9 +85,21 @@ struct zr_ctx {
     DevBuf<unsigned int> d_task;          // task-queue head of the persistent kernel
     DevBuf<unsigned char> d_overflow;     // per-wave BVH stack spill slabs
     int wf_blocks = 0;
-    int variant = 1;                      // 0 = pixel-group megakernel, 1 = wave-scheduler persistent kernel
+    int variant = 2;                      // 0 pixel-group megakernel, 1 wave-scheduler megakernel, 2 streaming wavefront pipeline
+    // variant 2: slot pool and per-frame buffers
+    DevBuf<unsigned char> d_pool;
+    DevBuf<uint32_t> d_pixels;
+    DevBuf<double> d_partial;
+    DevBuf<unsigned int> d_ctl;
+    DevBuf<unsigned char> d_st_overflow;
+    int st_blocks = 0;
+    uint32_t st_slots = 0;
+    unsigned int* h_active = nullptr;     // pinned
+    std::vector<int32_t> pix_key;         // plan the cached pixel list was built for
+    uint64_t last_rounds = 0;
+    double last_extend_ms = 0, last_shade_ms = 0;
     // device timing of render-kernel launches: HIP events recorded on the stream the kernel is launched on
-    struct Pending { hipEvent_t a, b; uint64_t render_id; };
+    struct Pending { hipEvent_t a, b; uint64_t render_id; int kind; };
     std::vector<hipEvent_t> pool;     // recycled events
     std::vector<Pending> pending;     // launches not yet resolved to milliseconds
     std::vector<float> log;           // resolved launch times since the last zr_get_kernel_times (oldest first)
@@ -361,7 +373,16 @@ zr_ctx* zr_create(int device_ordinal) {
         fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
-    c->variant = (int)env_double("ZR_KERNEL", 1);
+    c->variant = (int)env_double("ZR_KERNEL", 2);
+    if (c->variant == 2) {
+        c->st_blocks = zr::stream_extend_blocks();
+        int over = (int)env_double("ZR_ST_BLOCKS", 0);
+        if (over > 0) c->st_blocks = over;
+        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 4.0 * 1024 * 1024);
+        c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
+        if (c->d_ctl.alloc(16) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
+            hipHostMalloc((void**)&c->h_active, 64, 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
+    }
     if (c->variant == 1) {
         c->wf_blocks = zr::wavefront_max_blocks();
         int over = (int)env_double("ZR_WF_BLOCKS", 0);
@@ -378,6 +399,9 @@ void zr_destroy(zr_ctx* c) {
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_ctr.release(); c->d_out.release(); c->d_tiles.release();
+    c->d_pool.release(); c->d_pixels.release(); c->d_partial.release(); c->d_ctl.release(); c->d_st_overflow.release();
+    c->d_task.release(); c->d_overflow.release();
+    if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -630,6 +654,73 @@ int make_plan(const zr_camera& cam, const zr_region* region, Plan& p) {
 
 int resolve_times(zr_ctx* c);
 
+struct HostTimer : zr::StreamTimer {
+    zr_ctx* c; hipEvent_t cur_a = nullptr; bool ok = true;
+    explicit HostTimer(zr_ctx* c) : c(c) {}
+    hipEvent_t get() {
+        if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { ok = false; return nullptr; }
+        return e;
+    }
+    void begin(hipStream_t st, int) override { cur_a = get(); if (cur_a) (void)hipEventRecord(cur_a, st); }
+    void end(hipStream_t st, int kind) override {
+        hipEvent_t b = get();
+        if (!cur_a || !b) return;
+        (void)hipEventRecord(b, st);
+        zr_ctx::Pending pe{}; pe.a = cur_a; pe.b = b; pe.render_id = c->render_id; pe.kind = kind;
+        c->pending.push_back(pe);
+        cur_a = nullptr;
+    }
+};
+
+// variant 2: streaming wavefront pipeline (zr_stream.hip).  Synchronises the stream internally (the round loop
+// needs the active-slot count), so zr_render_device returns with the frame complete.
+int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr::DEnv& de, uint64_t seed, const Plan& plan, int count,
+                  double* d_out, hipStream_t stream, volatile const uint8_t* keep_going) {
+    // pixel list (cached per plan)
+    std::vector<int32_t> key = {plan.W, plan.H, plan.ts, plan.x0, plan.y0, plan.x1, plan.y1, (int32_t)plan.tiles.size(),
+                                plan.tiles.empty() ? -1 : plan.tiles.front(), plan.tiles.empty() ? -1 : plan.tiles.back()};
+    if (plan.W > 65535 || plan.H > 65535) return fail(ZR_E_INVALID, "kernel variant 2 supports frames up to 65535 x 65535");
+    if (key != c->pix_key || !c->d_pixels.p) {
+        std::vector<uint32_t> pix;
+        pix.reserve((size_t)plan.tiles.size() * plan.ts * plan.ts);
+        for (int32_t t : plan.tiles) {
+            int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+            int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+            for (int y = ya; y < yb; y++) for (int x = xa; x < xb; x++) pix.push_back((uint32_t)x | ((uint32_t)y << 16));
+        }
+        int rc = c->d_pixels.upload(pix);
+        if (rc) return rc;
+        c->pix_key = key;
+    }
+    const uint32_t n_pix = (uint32_t)c->d_pixels.n;
+    if (c->pending.size() > 65536) { int rr = resolve_times(c); if (rr) return rr; }
+    c->render_id++; c->last_stream = stream; c->last_counted = count != 0; c->last_rounds = 0;
+    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    if (n_pix == 0) return ZR_OK;
+    const uint32_t lanes = (uint32_t)plan.lanes;
+    uint32_t P = c->st_slots / lanes * lanes;
+    if ((uint64_t)n_pix * lanes < P) P = n_pix * lanes;
+    int rc;
+    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots)))) return rc;
+    const size_t partial_n = (size_t)n_pix * lanes * 3;
+    if (c->d_partial.n < partial_n) { if ((rc = c->d_partial.alloc(partial_n))) return rc; }
+    HIP_OK(hipMemsetAsync(c->d_partial.p, 0, partial_n * sizeof(double), stream));
+    HostTimer timer(c);
+    int rounds = 0;
+    hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, lanes, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
+                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, &timer, c->h_active, keep_going, &rounds);
+    if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
+    c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
+    unsigned int ctl[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpyAsync(ctl, c->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (ctl[2] != 0) return fail(ZR_E_DEVICE, "EXTEND kernel hit its iteration cap in %u wave(s)", ctl[2]);
+    if (rounds < 0) return fail(ZR_E_CANCELLED, "render cancelled after %d rounds", -rounds);
+    return ZR_OK;
+}
+
 int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const Plan& plan, int count,
                    double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done) {
     zr::DCamera dc; make_camera(*cam, dc);
@@ -642,6 +733,11 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
     HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    if (c->variant == 2 && dc.max_depth <= 250) {
+        int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going);
+        if (rows_done && r2 == ZR_OK) *rows_done = plan.H;
+        return r2;
+    }
     // one launch per frame unless the caller wants progress / cancellation, which need batch boundaries
     const bool interactive = keep_going || rows_done;
     const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", interactive ? 256 : (double)(1 << 30)));
@@ -664,7 +760,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
         wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
         wd.lanes_per_pixel = plan.lanes;
-        zr_ctx::Pending pe{}; pe.render_id = c->render_id;
+        zr_ctx::Pending pe{}; pe.render_id = c->render_id; pe.kind = 1;
         if ((rc = get_event(pe.a)) || (rc = get_event(pe.b))) return rc;
         HIP_OK(hipEventRecord(pe.a, stream));
         if (c->variant == 1)
@@ -693,8 +789,13 @@ int resolve_times(zr_ctx* c) {
         HIP_OK(hipEventSynchronize(p.b));
         float ms = 0;
         HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
-        c->log.push_back(ms);
-        if (p.render_id == c->render_id) { if (!fresh) { c->last_render_ms = 0; fresh = true; } c->last_render_ms += ms; }
+        if (p.kind == 1) c->log.push_back(ms);  // the dominant kernel's launches (render_* / stream_extend)
+        if (p.render_id == c->render_id) {
+            if (!fresh) { c->last_render_ms = 0; c->last_extend_ms = 0; c->last_shade_ms = 0; fresh = true; }
+            c->last_render_ms += ms;
+            if (p.kind == 1) c->last_extend_ms += ms;
+            if (p.kind == 2) c->last_shade_ms += ms;
+        }
         c->pool.push_back(p.a); c->pool.push_back(p.b);
     }
     c->pending.clear();
@@ -757,6 +858,7 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (rc) return rc;
     std::memset(out, 0, sizeof *out);
     out->kernel_ms = c->last_render_ms;
+    out->extend_ms = c->last_extend_ms; out->shade_ms = c->last_shade_ms; out->rounds = c->last_rounds;
     unsigned long long h[16];
     HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[15] != 0) return fail(ZR_E_DEVICE, "render kernel hit its iteration cap on %llu task(s): results are incomplete", h[15]);

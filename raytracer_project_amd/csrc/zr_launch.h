@@ -29,6 +29,19 @@ int wavefront_max_blocks();
 hipError_t launch_render_wavefront(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
                                    unsigned long long* gctr, bool count, unsigned int* task_counter, void* overflow, int max_blocks,
                                    hipStream_t stream);
+// variant 2: streaming wavefront pipeline (zr_stream.hip)
+struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 extend, 2 shade, 3 reduce
+    virtual void begin(hipStream_t, int kind) = 0;
+    virtual void end(hipStream_t, int kind) = 0;
+    virtual ~StreamTimer() = default;
+};
+size_t stream_overflow_bytes(int blocks);
+int stream_extend_blocks();
+size_t stream_pool_bytes(uint32_t P);
+hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t lanes,
+                         uint32_t n_pix, const uint32_t* d_pixels, double* d_partial, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
+                         double* out, unsigned long long* gctr, bool count, hipStream_t stream, StreamTimer* timer,
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out);
 hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
                         uint32_t bounce, zr_hit* out, hipStream_t stream);
 

@@ -1,15 +1,7 @@
-cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python3 - <<'PY'
-import sys; sys.path.insert(0,'.')
-from raytracer_project_amd import capi
-ctx=capi.Context(0)
-for name,spp in (('cfg3',512),('cfg2',256),('cfg5',256)):
-    ds=capi.DemoScene(name); cam=ds.camera.copy(); cam.samples_per_pixel=spp
-    sc=capi.Scene(ctx,ds.desc); sc.render(cam,ds.env,ds.seed,None,count=True); c=ctx.counters()
-    d=c.as_dict(); seg=d['segments']
-    sc.render(cam,ds.env,ds.seed,None,count=False); c2=ctx.counters()
-    print(name, 'Mseg/s %.1f'%(seg/c2.kernel_ms*1e-3), 'boxes/seg %.1f'%(d['nodes_tested']/seg), 'tri/seg %.2f'%(d['triangles_tested']/seg), 'sph/seg %.2f'%(d['spheres_tested']/seg),'cube/seg %.2f'%(d['cubes_tested']/seg), 'hit frac %.2f'%(d['hits']/seg))
-    for ph in ('node','leaf','shade'):
-        e=d[ph+'_execs']; l=d[ph+'_lanes']; print('   %-5s execs/seg*64 %.2f  avg lanes %.1f'%(ph, e*64/seg, l/max(e,1)))
-PY
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/pmc*
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $R/gpurun_out/pmc1 -- python3 $R/bench.py --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > $R/gpurun_out/pmc1.json 2> $R/gpurun_out/pmc1.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM --output-format csv -d $R/gpurun_out/pmc2 -- python3 $R/bench.py --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > $R/gpurun_out/pmc2.json 2> $R/gpurun_out/pmc2.err
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/pmc3 -- python3 $R/bench.py --steps 1 --warmup 0 --spp 32 --no-cpu-baseline > $R/gpurun_out/pmc3.json 2> $R/gpurun_out/pmc3.err || true
