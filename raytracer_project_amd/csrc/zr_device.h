@@ -253,13 +253,21 @@ __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, c
 }
 
 // ---- primitives: full hit record of the winner ------------------------------------------------------
-__device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // sphere.hpp:42-79
+// `full` = false: u, v, tangent, bitangent are only computed when the hit's material reads them (a texture that
+// depends on u/v, or a bump map: zr_material::pad_ set by the host).  They are pure functions of the hit, so
+// skipping them when nothing consumes them cannot change any result; the reference computes acos/atan2 on every
+// accepted candidate (sphere.hpp:47,70-79).
+__device__ __forceinline__ bool mat_needs_uv(const DScene& sc, uint32_t mat) { return mat < sc.n_mats && sc.mats[mat].pad_ != 0; }
+
+__device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec, bool full) {  // sphere.hpp:42-79
     const double* s = sc.spheres + (size_t)idx * 4;
     V3 center = mk(s[0], s[1], s[2]);
     rec.t = t;
     rec.p = at(r, t);
     V3 outward = vdiv(rec.p - center, s[3]);
     set_face(rec, r.d, outward);
+    rec.mat = sc.sphere_mat[idx];
+    if (!full && !mat_needs_uv(sc, rec.mat)) { rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0); return; }
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + 3.14159265358979323846;
     rec.u = phi / (2 * 3.14159265358979323846);
@@ -268,7 +276,6 @@ __device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, 
     if (len2(rec.tan) < 0.001) rec.tan = cross(mk(0, 0, 1), rec.n);
     rec.tan = unit(rec.tan);
     rec.bit = cross(rec.n, rec.tan);
-    rec.mat = sc.sphere_mat[idx];
 }
 
 __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // triangle.hpp:40-79
@@ -317,8 +324,8 @@ __device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, do
     set_face(rec, r.d, rec.n);
 }
 
-__device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec) {
-    if (kind == ZR_PRIM_SPHERE) sphere_rec(sc, idx, r, t, rec);
+__device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full) {
+    if (kind == ZR_PRIM_SPHERE) sphere_rec(sc, idx, r, t, rec, full);
     else if (kind == ZR_PRIM_CUBE) cube_rec(sc, idx, r, t, rec);
     else if (kind == ZR_PRIM_TRIANGLE) triangle_rec(sc, idx, r, t, rec);
     else {  // medium: constant_medium.hpp:70-75
@@ -332,11 +339,12 @@ __device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, c
 }
 
 // hit record of leaf object (kind, idx) hit by world ray r at distance t
-__device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec) {
-    if (kind != ZR_KIND_WRAPPED) { bare_rec(sc, kind, idx, r, t, rec); return; }
+// `full`: compute every field (known-answer entry); otherwise u/v/tangent only when the material reads them
+__device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full = false) {
+    if (kind != ZR_KIND_WRAPPED) { bare_rec(sc, kind, idx, r, t, rec, full); return; }
     const DWrapped w = sc.wrapped[idx];
     Ray lr = chain_ray(sc, w.chain_first, w.chain_count, r);
-    bare_rec(sc, w.type, w.index, lr, t, rec);
+    bare_rec(sc, w.type, w.index, lr, t, rec, true);  // a material_instance in the chain may replace the material
     for (int k = (int)w.chain_count - 1; k >= 0; k--) {
         Ray outer = chain_ray(sc, w.chain_first, (uint32_t)k, r);
         apply_op_rec(sc.ops[w.chain_first + k], outer.d, rec);
@@ -553,6 +561,26 @@ __device__ inline V3 background(const DScene& sc, const DEnv& env, V3 rd) {
         double y3 = env.sr * d.x + env.cr * d.y;
         d = mk(x3, y3, d.z);
         const double PI = 3.14159265358979323846;
+        const zr_texture& t = sc.texs[env.hdr_tex];
+        if (t.kind == ZR_TEX_IMAGE_F32 && t.width > 0 && t.height > 0 && t.width <= 16384 && t.height <= 16384) {
+            // Only the TEXEL INDEX of (u, v) matters (nearest lookup, texture.hpp:60-66).  Get it from FP32
+            // atan2f/acosf, and fall back to the FP64 functions only when the FP32 coordinate lies within
+            // `guard` texels of a texel boundary (or near the poles, where acos is ill-conditioned): the FP32
+            // path's absolute error is below 4e-6 rad (2 ulp functions + input rounding), i.e. < 0.011 texel at
+            // 16384 texels, so inside the guarded interior both paths select the same texel.
+            const float xf = (float)d.x, yf = (float)d.y, zf = (float)d.z;
+            const float PIf = 3.14159265358979323846f;
+            const float fi = (atan2f(zf, xf) + PIf) * (0.15915494309189535f * (float)t.width);
+            const float fj = acosf(fminf(fmaxf(yf, -1.0f), 1.0f)) * (0.3183098861837907f * (float)t.height);
+            const float ri = fi - floorf(fi), rj = fj - floorf(fj);
+            const float guard = 0.02f;
+            if (fabsf(yf) < 0.999f && ri > guard && ri < 1.0f - guard && rj > guard && rj < 1.0f - guard && fi > guard &&
+                fi < (float)t.width - guard) {
+                const int i = (int)fi, j = (int)fj;
+                const float* px = (const float*)(sc.texels + t.texel_offset) + ((size_t)j * t.width + i) * 3;
+                return mk((double)px[0], (double)px[1], (double)px[2]) * env.intensity;
+            }
+        }
         double phi = atan2(d.z, d.x) + PI;
         double theta = acos(clampd(d.y, -1.0, 1.0));
         return tex_value(sc, env.hdr_tex, phi / (2 * PI), theta / PI, mk(0, 0, 0)) * env.intensity;

@@ -378,9 +378,9 @@ zr_ctx* zr_create(int device_ordinal) {
         c->st_blocks = zr::stream_extend_blocks();
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
         if (over > 0) c->st_blocks = over;
-        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 4.0 * 1024 * 1024);
+        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 16.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
-        if (c->d_ctl.alloc(16) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
+        if (c->d_ctl.alloc(zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
             hipHostMalloc((void**)&c->h_active, 64, 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
     if (c->variant == 1) {
@@ -537,7 +537,24 @@ int zr_scene_commit(zr_scene* s) {
     if ((rc = s->d_media.upload(fl.media))) return rc;
     if ((rc = s->d_wrapped.upload(fl.wrapped))) return rc;
     if ((rc = s->d_ops.upload(s->ops))) return rc;
-    if ((rc = s->d_mats.upload(s->materials))) return rc;
+    {
+        // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
+        // texture tree, or a bump map) -> the kernels compute those hit-record fields only then
+        std::vector<zr_material> mats = s->materials;
+        auto tex_uses_uv = [&](uint32_t id) {
+            std::vector<uint32_t> todo{id}; int guard = 0;
+            while (!todo.empty() && guard++ < 4096) {
+                uint32_t t = todo.back(); todo.pop_back();
+                if (t >= s->textures.size()) continue;
+                const zr_texture& tx = s->textures[t];
+                if (tx.kind >= ZR_TEX_IMAGE_U8) return true;
+                if (tx.kind == ZR_TEX_CHECKER) { todo.push_back(tx.odd); todo.push_back(tx.even); }
+            }
+            return guard >= 4096;
+        };
+        for (zr_material& m : mats) m.pad_ = (m.bump_tex != ZR_NO_TEXTURE || (m.kind != ZR_MAT_DIELECTRIC && tex_uses_uv(m.tex))) ? 1u : 0u;
+        if ((rc = s->d_mats.upload(mats))) return rc;
+    }
     if ((rc = s->d_texs.upload(s->textures))) return rc;
     if ((rc = s->d_texels.upload(s->texels))) return rc;
 
@@ -701,6 +718,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     if (n_pix == 0) return ZR_OK;
     const uint32_t lanes = (uint32_t)plan.lanes;
     uint32_t P = c->st_slots / lanes * lanes;
+    if ((uint64_t)n_pix * lanes > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x lanes must fit 32 bits)");
     if ((uint64_t)n_pix * lanes < P) P = n_pix * lanes;
     int rc;
     if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots)))) return rc;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* 
     zr_hit o;
     if (h && t < tmax) {
         Rec rec;
-        object_rec(sc, kind, idx, r, t, rec);
+        object_rec(sc, kind, idx, r, t, rec, true);
         o.p[0] = rec.p.x; o.p[1] = rec.p.y; o.p[2] = rec.p.z;
         o.normal[0] = rec.n.x; o.normal[1] = rec.n.y; o.normal[2] = rec.n.z;
         o.tangent[0] = rec.tan.x; o.tangent[1] = rec.tan.y; o.tangent[2] = rec.tan.z;

@@ -36,6 +36,7 @@ struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 exten
     virtual ~StreamTimer() = default;
 };
 size_t stream_overflow_bytes(int blocks);
+size_t stream_ctl_words();
 int stream_extend_blocks();
 size_t stream_pool_bytes(uint32_t P);
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t lanes,

@@ -14,8 +14,10 @@
 //   end:    REDUCE  slot sums were written to partial[pixel][lane] when a slot left a pixel; one fixed-order sum
 //                   per pixel gives the mean — no atomics on radiance anywhere, the image is bit-reproducible
 //
-// Slot -> work mapping is static: group g = slot / LANES owns pixels g, g + G, g + 2G, ... of the frame's pixel
-// list, lane j of the group owns samples j, j + LANES, ... of the group's current pixel.
+// Work units: unit u = (pixel u / LANES of the frame's pixel list, lane j = u % LANES) = samples j, j + LANES, ... of
+// that pixel.  Slot k starts on unit k; a slot that finishes its unit writes its sum to partial[pixel][j] and takes
+// the next unit from one of ST_SHARDS interleaved counters (one atomic per wave per round, spread over ST_SHARDS
+// cache lines).  Which slot computes a unit does not affect the unit's value, so the image is deterministic.
 #include "zr_device.h"
 #include "zr_launch.h"
 
@@ -25,8 +27,12 @@ namespace zr {
 #define ST_EXT_WAVES 4  /* waves per SIMD the EXTEND kernel's register budget must allow */
 #endif
 #ifndef ST_CHUNK
-#define ST_CHUNK 512    /* rays a wave reserves per global atomic */
+#define ST_CHUNK 256    /* rays a wave reserves per global atomic */
 #endif
+#ifndef ST_SHADE_WAVES
+#define ST_SHADE_WAVES 2 /* 256-thread blocks per CU (= waves per SIMD) the SHADE kernel must fit */
+#endif
+#define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #define ST_LDS_STACK 8
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
@@ -43,20 +49,20 @@ struct StreamBuf {
     double* att0;   // [3][P]
     double* sum;    // [3][P]
     unsigned long long* key;  // [P]
-    uint4* meta;    // [P] x = RNG draw index, y = bounce | b_inner << 8 | flags, z = pixel-list index, w = sample
+    uint4* meta;    // [P] x = RNG draw index, y = bounce | b_inner << 8 | flags, z = work unit, w = sample
     const uint32_t* pixels;   // [n_pix] px | py << 16
     double* partial;          // [n_pix][lanes][3]
-    unsigned int* ctl;        // [0] extend head, [1] active slots after the last SHADE, [2] iteration-cap hits
-    uint32_t P, lanes, groups, n_pix;
+    unsigned int* ctl;        // [0] extend head, [1] active slots after the last SHADE, [2] iteration-cap hits, [16 + 32 s] unit counters
+    uint32_t P, lanes, n_units, n_pix;
 };
 
 __device__ __forceinline__ double ldnt(const double* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stnt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
 // ---- begin a sample in a slot: camera ray + fresh path state --------------------------------------------
-__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t pix_i, uint32_t sample,
+__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t sample,
                                     uint32_t& c_samp) {
-    const uint32_t pk = B.pixels[pix_i];
+    const uint32_t pk = B.pixels[unit / B.lanes];
     const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
     Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)sample); g.k = 0; g.bounce = 0;
     Ray r = camera_ray(cam, px, py, g);
@@ -64,7 +70,7 @@ __device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint
     stnt(B.ray + 0 * P + slot, r.o.x); stnt(B.ray + 1 * P + slot, r.o.y); stnt(B.ray + 2 * P + slot, r.o.z);
     stnt(B.ray + 3 * P + slot, r.d.x); stnt(B.ray + 4 * P + slot, r.d.y); stnt(B.ray + 5 * P + slot, r.d.z);
     B.key[slot] = g.key;
-    uint4 m; m.x = (uint32_t)g.k; m.y = F_FIRST | F_ACTIVE; m.z = pix_i; m.w = sample;
+    uint4 m; m.x = (uint32_t)g.k; m.y = F_FIRST | F_ACTIVE; m.z = unit; m.w = sample;
     B.meta[slot] = m;
     c_samp++;
 }
@@ -73,11 +79,10 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uint64_t seed, unsigned long long* __restrict__ gctr) {
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= B.P) return;
-    const uint32_t g = slot / B.lanes, j = slot % B.lanes;
     const size_t P = B.P;
     for (int c = 0; c < 3; c++) B.sum[c * P + slot] = 0.0;
     uint32_t c_samp = 0;
-    if (g < B.n_pix) begin_sample(B, cam, seed, slot, g, j, c_samp);
+    if (slot < B.n_units) begin_sample(B, cam, seed, slot, slot, slot % B.lanes, c_samp);
     else { uint4 m; m.x = 0; m.y = 0; m.z = 0; m.w = 0; B.meta[slot] = m; }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
@@ -288,11 +293,11 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
 
 // ---- SHADE: one segment of every active slot ------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(256) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
+__global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
                                                     unsigned long long* __restrict__ gctr) {
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     if (slot == 0) B.ctl[0] = 0;  // EXTEND of the next round starts from ray 0 again
-    bool active_after = false;
+    bool active_after = false, want_unit = false;
     uint32_t c_samp = 0; unsigned long long c_draws = 0;
     if (slot < B.P) {
         uint4 m = B.meta[slot];
@@ -364,17 +369,35 @@ __global__ __launch_bounds__(256) void stream_shade(DScene sc, DCamera cam, DEnv
             } else {
                 sum = sum + contrib;
                 if (COUNT) c_draws += g.k;
-                // next sample of this slot: same pixel, or the group's next pixel
-                uint32_t pix_i = m.z, sample = m.w + B.lanes;
-                if (sample >= (uint32_t)cam.spp) {
-                    double* pp = B.partial + ((size_t)pix_i * B.lanes + slot % B.lanes) * 3;
+                // next sample of this unit, or a new unit
+                uint32_t sample = m.w + B.lanes;
+                if (sample < (uint32_t)cam.spp) {
+                    B.sum[slot] = sum.x; B.sum[P + slot] = sum.y; B.sum[2 * P + slot] = sum.z;
+                    begin_sample(B, cam, seed, slot, m.z, sample, c_samp);
+                    active_after = true;
+                } else {
+                    double* pp = B.partial + (size_t)m.z * 3;  // = [pixel][lane][3]
                     pp[0] = sum.x; pp[1] = sum.y; pp[2] = sum.z;
-                    sum = mk(0, 0, 0);
-                    pix_i += B.groups; sample = slot % B.lanes;
+                    B.sum[slot] = 0.0; B.sum[P + slot] = 0.0; B.sum[2 * P + slot] = 0.0;
+                    want_unit = true;
                 }
-                B.sum[slot] = sum.x; B.sum[P + slot] = sum.y; B.sum[2 * P + slot] = sum.z;
-                if (pix_i < B.n_pix) { begin_sample(B, cam, seed, slot, pix_i, sample, c_samp); active_after = true; }
-                else { m.y = 0; B.meta[slot] = m; }
+            }
+        }
+    }
+    // hand out new work units: one atomic per wave on this block's shard
+    {
+        const unsigned long long wm = __ballot(want_unit);
+        if (wm != 0ull) {
+            const uint32_t shard = blockIdx.x % ST_SHARDS;
+            const int wl = threadIdx.x & 63;
+            uint32_t k0 = 0;
+            if (wl == (int)__builtin_ctzll(wm)) k0 = atomicAdd(&B.ctl[16 + 32 * shard], (unsigned int)__popcll(wm));
+            k0 = __shfl(k0, (int)__builtin_ctzll(wm), 64);
+            if (want_unit) {
+                const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
+                const unsigned long long u = (unsigned long long)B.P + k * ST_SHARDS + shard;
+                if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, (uint32_t)(u % B.lanes), c_samp); active_after = true; }
+                else { uint4 m0; m0.x = 0; m0.y = 0; m0.z = 0; m0.w = 0; B.meta[slot] = m0; }
             }
         }
     }
@@ -400,6 +423,7 @@ __global__ __launch_bounds__(256) void stream_reduce(StreamBuf B, DCamera cam, d
 }
 
 // ---- host-side launch helpers -----------------------------------------------------------------------------------
+size_t stream_ctl_words() { return 16 + 32 * ST_SHARDS; }
 size_t stream_overflow_bytes(int blocks) { return (size_t)blocks * ST_OVERFLOW * 64 * sizeof(SEntry); }
 
 int stream_extend_blocks() {
@@ -417,7 +441,7 @@ size_t stream_pool_bytes(uint32_t P) {
     return (size_t)P * (6 * 8 + 8 + 8 + 4 * 3 * 8 + 8 + 16) + 4096;
 }
 
-static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t groups, uint32_t n_pix, const uint32_t* pixels, double* partial,
+static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t n_units, uint32_t n_pix, const uint32_t* pixels, double* partial,
                           unsigned int* ctl) {
     StreamBuf B;
     unsigned char* p = (unsigned char*)pool;
@@ -431,7 +455,7 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t group
     B.key = (unsigned long long*)p; p += (size_t)P * 8;
     B.meta = (uint4*)p;
     B.pixels = pixels; B.partial = partial; B.ctl = ctl;
-    B.P = P; B.lanes = lanes; B.groups = groups; B.n_pix = n_pix;
+    B.P = P; B.lanes = lanes; B.n_units = n_units; B.n_pix = n_pix;
     return B;
 }
 
@@ -439,10 +463,10 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_partial, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t stream, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out) {
-    const uint32_t groups = P / lanes;
-    StreamBuf B = make_buf(pool, P, lanes, groups, n_pix, d_pixels, d_partial, d_ctl);
+    const uint32_t n_units = n_pix * lanes;
+    StreamBuf B = make_buf(pool, P, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl);
     hipError_t e;
-    if ((e = hipMemsetAsync(d_ctl, 0, 16 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_ctl, 0, stream_ctl_words() * sizeof(unsigned int), stream)) != hipSuccess) return e;
     const unsigned pblocks = (P + 255) / 256;
     if (timer) timer->begin(stream, 0);
     if (count) hipLaunchKernelGGL(stream_init<true>, dim3(pblocks), dim3(256), 0, stream, B, cam, seed, gctr);
