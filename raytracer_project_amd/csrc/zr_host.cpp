@@ -103,6 +103,7 @@ struct zr_ctx {
     std::vector<hipEvent_t> pool;     // recycled events
     std::vector<Pending> pending;     // launches not yet resolved to milliseconds
     std::vector<float> log;           // resolved launch times since the last zr_get_kernel_times (oldest first)
+    int log_kind = 1;                 // ZR_TIMELOG_KIND: which kernel zr_get_kernel_times reports (1 extend/render, 2 shade)
     uint64_t render_id = 0;
     double last_render_ms = 0;        // sum over the launches of the most recent render call
     hipStream_t last_stream = nullptr;
@@ -374,6 +375,7 @@ zr_ctx* zr_create(int device_ordinal) {
     }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
     c->variant = (int)env_double("ZR_KERNEL", 2);
+    c->log_kind = (int)env_double("ZR_TIMELOG_KIND", 1);
     if (c->variant == 2) {
         c->st_blocks = zr::stream_extend_blocks();
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
@@ -807,7 +809,7 @@ int resolve_times(zr_ctx* c) {
         HIP_OK(hipEventSynchronize(p.b));
         float ms = 0;
         HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
-        if (p.kind == 1) c->log.push_back(ms);  // the dominant kernel's launches (render_* / stream_extend)
+        if (p.kind == c->log_kind) c->log.push_back(ms);  // default: the dominant kernel's launches (render_* / stream_extend)
         if (p.render_id == c->render_id) {
             if (!fresh) { c->last_render_ms = 0; c->last_extend_ms = 0; c->last_shade_ms = 0; fresh = true; }
             c->last_render_ms += ms;

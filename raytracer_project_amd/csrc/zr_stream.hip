@@ -40,24 +40,30 @@ enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17 };  // meta.y: bounce | b_inner <
 
 struct SEntry { uint32_t node; float tn; };
 
+// Slot pool layout: array of 64-slot blocks, each block = SF_N rows of 64 x 8 bytes ([block][field][lane]).  A wave
+// that works on 64 consecutive slots touches one contiguous 12 KB block, every field access is one coalesced
+// 512-B row, and all of a slot's state shares a page (a plain [field][P] layout put each of the 23 fields 128 MB
+// apart and ran the SHADE stage at 1.7 TB/s).
+enum { SF_RAY = 0, SF_HIT_T = 6, SF_HIT_KI = 7, SF_BETA = 8, SF_L = 11, SF_ATT0 = 14, SF_SUM = 17, SF_KEY = 20,
+       SF_MA = 21 /* RNG draw index, bounce | b_inner << 8 | flags */, SF_MB = 22 /* work unit, sample */, SF_N = 24 };
+
 struct StreamBuf {
-    double* ray;    // [6][P]
-    double* hit_t;  // [P]
-    uint2* hit_ki;  // [P] kind, index (kind = 0xFFFFFFFF: miss)
-    double* beta;   // [3][P]
-    double* L;      // [3][P]
-    double* att0;   // [3][P]
-    double* sum;    // [3][P]
-    unsigned long long* key;  // [P]
-    uint4* meta;    // [P] x = RNG draw index, y = bounce | b_inner << 8 | flags, z = work unit, w = sample
+    double* pool;             // [P / 64][SF_N][64] 8-byte cells
     const uint32_t* pixels;   // [n_pix] px | py << 16
     double* partial;          // [n_pix][lanes][3]
-    unsigned int* ctl;        // [0] extend head, [1] active slots after the last SHADE, [2] iteration-cap hits, [16 + 32 s] unit counters
+    unsigned int* ctl;        // [1] active slots after the last SHADE, [2] iteration-cap hits; per shard s: [16 + 32 s] unit counter,
+                              // [16 + 32 s + 8] EXTEND chunk head (ST_SHARDS words on separate cache lines: a single
+                              // contended word sustains only ~90 atomics/us)
     uint32_t P, lanes, n_units, n_pix;
+    __device__ __forceinline__ double* cell(int f, uint32_t slot) const { return pool + ((size_t)(slot >> 6) * SF_N + f) * 64 + (slot & 63u); }
+    __device__ __forceinline__ double ld(int f, uint32_t slot) const { return *cell(f, slot); }
+    __device__ __forceinline__ void st(int f, uint32_t slot, double v) const { *cell(f, slot) = v; }
+    __device__ __forceinline__ uint2 ld2(int f, uint32_t slot) const { return *reinterpret_cast<const uint2*>(cell(f, slot)); }
+    __device__ __forceinline__ void st2(int f, uint32_t slot, uint2 v) const { *reinterpret_cast<uint2*>(cell(f, slot)) = v; }
+    __device__ __forceinline__ V3 ld3(int f, uint32_t slot) const { return mk(ld(f, slot), ld(f + 1, slot), ld(f + 2, slot)); }
+    __device__ __forceinline__ void st3(int f, uint32_t slot, V3 v) const { st(f, slot, v.x); st(f + 1, slot, v.y); st(f + 2, slot, v.z); }
 };
 
-__device__ __forceinline__ double ldnt(const double* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void stnt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 
 // ---- begin a sample in a slot: camera ray + fresh path state --------------------------------------------
 __device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t sample,
@@ -66,12 +72,11 @@ __device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint
     const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
     Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)sample); g.k = 0; g.bounce = 0;
     Ray r = camera_ray(cam, px, py, g);
-    const size_t P = B.P;
-    stnt(B.ray + 0 * P + slot, r.o.x); stnt(B.ray + 1 * P + slot, r.o.y); stnt(B.ray + 2 * P + slot, r.o.z);
-    stnt(B.ray + 3 * P + slot, r.d.x); stnt(B.ray + 4 * P + slot, r.d.y); stnt(B.ray + 5 * P + slot, r.d.z);
-    B.key[slot] = g.key;
-    uint4 m; m.x = (uint32_t)g.k; m.y = F_FIRST | F_ACTIVE; m.z = unit; m.w = sample;
-    B.meta[slot] = m;
+    B.st3(SF_RAY, slot, r.o); B.st3(SF_RAY + 3, slot, r.d);
+    B.st(SF_KEY, slot, __longlong_as_double((long long)g.key));
+    uint2 ma; ma.x = (uint32_t)g.k; ma.y = F_FIRST | F_ACTIVE;
+    uint2 mb; mb.x = unit; mb.y = sample;
+    B.st2(SF_MA, slot, ma); B.st2(SF_MB, slot, mb);
     c_samp++;
 }
 
@@ -79,11 +84,10 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uint64_t seed, unsigned long long* __restrict__ gctr) {
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= B.P) return;
-    const size_t P = B.P;
-    for (int c = 0; c < 3; c++) B.sum[c * P + slot] = 0.0;
+    B.st3(SF_SUM, slot, mk(0, 0, 0));
     uint32_t c_samp = 0;
     if (slot < B.n_units) begin_sample(B, cam, seed, slot, slot, slot % B.lanes, c_samp);
-    else { uint4 m; m.x = 0; m.y = 0; m.z = 0; m.w = 0; B.meta[slot] = m; }
+    else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
 
@@ -99,8 +103,6 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
     SEntry* gstack = overflow + (size_t)blockIdx.x * ST_OVERFLOW * 64 + lane;
     const double INF = __builtin_huge_val();
     const uint32_t NONE = 0xFFFFFFFFu;
-    const size_t P = B.P;
-
     int st = X_IDLE;
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
     Rng g; g.key = 0; g.k = 0; g.bounce = 0;  // only the medium test reads it
     bool work_left = true;
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the private range of ray indices being handed out
+    uint32_t head_shard = blockIdx.x % ST_SHARDS, shards_tried = 0;
     if (blockIdx.x == 0 && lane == 0) B.ctl[1] = 0;  // SHADE of this round recounts the active slots
     uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_cube = 0, c_med = 0, c_seg = 0, c_hits = 0;
     unsigned long long s_exec[2] = {0, 0}, s_lanes[2] = {0, 0};
@@ -125,14 +128,14 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
         }
     };
     auto finish = [&]() {  // traversal of this lane's ray is complete: publish the result
-        stnt(B.hit_t + slot, tbest);
+        B.st(SF_HIT_T, slot, tbest);
         uint2 ki; ki.x = kbest; ki.y = ibest;
-        B.hit_ki[slot] = ki;
+        B.st2(SF_HIT_KI, slot, ki);
         if (COUNT && kbest != NONE) c_hits++;
         st = X_IDLE;
     };
 
-    const unsigned long long iter_cap = (unsigned long long)P * 64ull + (1ull << 24);
+    const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
     unsigned long long iter = 0;
     for (; iter < iter_cap; iter++) {
         const uint32_t lkind = (pa_meta >> 16) - 1u;
@@ -150,14 +153,21 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
             // contended word sustains only ~90 atomics/us on this chip)
             const unsigned long long idle = __ballot(st == X_IDLE);
             uint32_t n = (uint32_t)__popcll(idle);
-            if (chunk_next >= chunk_end) {
+            while (chunk_next >= chunk_end && work_left) {
+                // reserve the next chunk of this wave's shard; an exhausted shard sends the wave to the next one
                 uint32_t nb = 0;
-                if (lane == 0) nb = atomicAdd(&B.ctl[0], (unsigned int)ST_CHUNK);
+                if (lane == 0) nb = atomicAdd(&B.ctl[16 + 32 * head_shard + 8], 1u);
                 nb = __builtin_amdgcn_readfirstlane(nb);
-                chunk_next = nb < B.P ? nb : B.P;
-                chunk_end = nb + ST_CHUNK < B.P ? nb + ST_CHUNK : B.P;
-                if (chunk_next >= chunk_end) work_left = false;
+                const unsigned long long first = ((unsigned long long)nb * ST_SHARDS + head_shard) * ST_CHUNK;
+                if (first < (unsigned long long)B.P) {
+                    chunk_next = (uint32_t)first;
+                    chunk_end = first + ST_CHUNK < (unsigned long long)B.P ? (uint32_t)first + ST_CHUNK : B.P;
+                } else {
+                    head_shard = (head_shard + 1) % ST_SHARDS;
+                    if (++shards_tried >= ST_SHARDS) work_left = false;
+                }
             }
+            if (!work_left) n = 0;
             if (n > chunk_end - chunk_next) n = chunk_end - chunk_next;
             const uint32_t base = chunk_next;
             chunk_next += n;
@@ -165,12 +175,11 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
             if (st == X_IDLE) {
                 const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
                 if (my < lim) {
-                    const uint4 m = B.meta[my];
+                    const uint2 m = B.ld2(SF_MA, my);
                     if (m.y & F_ACTIVE) {
                         slot = my;
-                        ray.o = mk(ldnt(B.ray + 0 * P + my), ldnt(B.ray + 1 * P + my), ldnt(B.ray + 2 * P + my));
-                        ray.d = mk(ldnt(B.ray + 3 * P + my), ldnt(B.ray + 4 * P + my), ldnt(B.ray + 5 * P + my));
-                        g.key = B.key[my]; g.bounce = m.y & 0xFFu;
+                        ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
+                        g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu;
                         idx_ = 1.0 / ray.d.x; idy_ = 1.0 / ray.d.y; idz_ = 1.0 / ray.d.z;
                         ox_ = ray.o.x * idx_; oy_ = ray.o.y * idy_; oz_ = ray.o.z * idz_;
                         tbest = INF; kbest = NONE; cur = 0; sp = 0; pa_meta = 0; pb_meta = 0; pend_i = 0;
@@ -296,49 +305,51 @@ template <bool COUNT>
 __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
                                                     unsigned long long* __restrict__ gctr) {
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot == 0) B.ctl[0] = 0;  // EXTEND of the next round starts from ray 0 again
+    if (slot < ST_SHARDS) B.ctl[16 + 32 * slot + 8] = 0;  // EXTEND of the next round starts from chunk 0 of every shard
     bool active_after = false, want_unit = false;
     uint32_t c_samp = 0; unsigned long long c_draws = 0;
     if (slot < B.P) {
-        uint4 m = B.meta[slot];
+        uint2 m = B.ld2(SF_MA, slot);
         if (m.y & F_ACTIVE) {
-            const size_t P = B.P;
             const uint32_t NONE = 0xFFFFFFFFu;
-            Ray ray;
-            ray.o = mk(ldnt(B.ray + 0 * P + slot), ldnt(B.ray + 1 * P + slot), ldnt(B.ray + 2 * P + slot));
-            ray.d = mk(ldnt(B.ray + 3 * P + slot), ldnt(B.ray + 4 * P + slot), ldnt(B.ray + 5 * P + slot));
-            const double t = ldnt(B.hit_t + slot);
-            const uint2 ki = B.hit_ki[slot];
-            Rng g; g.key = B.key[slot]; g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this closest-hit query is complete
+            const uint2 mb = B.ld2(SF_MB, slot);
+            Ray ray; ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
+            const uint2 ki = B.ld2(SF_HIT_KI, slot);
+            Rng g; g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, slot)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
             int b_inner = (int)((m.y >> 8) & 0xFFu);
             const bool first = (m.y & F_FIRST) != 0;
             const int depth_inner = cam.max_depth - 1;
-            V3 L = mk(0, 0, 0), beta = mk(1, 1, 1), att0 = mk(1, 1, 1);
-            if (!first) {
-                L = mk(B.L[slot], B.L[P + slot], B.L[2 * P + slot]);
-                beta = mk(B.beta[slot], B.beta[P + slot], B.beta[2 * P + slot]);
-                att0 = mk(B.att0[slot], B.att0[P + slot], B.att0[2 * P + slot]);
-            }
-            V3 sum = mk(B.sum[slot], B.sum[P + slot], B.sum[2 * P + slot]);
-            bool ended = false, cont_first = false;
-            V3 contrib = mk(0, 0, 0);
-            Ray nr; nr.o = mk(0, 0, 0); nr.d = mk(0, 0, 1);
+            // L, att0 and the slot's running sum are read only on the paths that need them
+            bool ended = false;
+            V3 contrib = mk(0, 0, 0);   // added to the slot sum when the path ends
+            V3 add_now = mk(0, 0, 0);   // emission of a primary hit: added to the slot sum immediately
+            bool has_add = false;
             if (ki.x == NONE) {
                 V3 bg = background(sc, env, ray.d);
-                contrib = first ? bg : att0 * (L + beta * bg);   // camera.hpp:520 / 941,1000
+                contrib = first ? bg : B.ld3(SF_ATT0, slot) * (B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg);  // camera.hpp:520 / 941,1000
                 ended = true;
             } else {
-                Rec rec;
-                object_rec(sc, ki.x, ki.y, ray, t, rec);
-                V3 em = emitted(sc, rec);
-                V3 att;
-                const bool sc_ok = scatter(sc, ray, rec, att, nr, g);
+                const double t = B.ld(SF_HIT_T, slot);
+                V3 em, att; Ray nr; bool sc_ok;
+                {
+                    Rec rec;
+                    object_rec(sc, ki.x, ki.y, ray, t, rec);
+                    em = emitted(sc, rec);
+                    sc_ok = scatter(sc, ray, rec, att, nr, g);
+                }
+                const bool has_em = em.x != 0.0 || em.y != 0.0 || em.z != 0.0;
                 if (first) {  // ray_color_from_hit, camera.hpp:989-1004
-                    sum = sum + em;
+                    if (has_em) { add_now = em; has_add = true; }
                     if (!sc_ok || depth_inner <= 0) ended = true;
-                    else { att0 = att; L = mk(0, 0, 0); beta = mk(1, 1, 1); b_inner = 0; cont_first = true; }
+                    else {
+                        B.st3(SF_ATT0, slot, att); B.st3(SF_L, slot, mk(0, 0, 0)); B.st3(SF_BETA, slot, mk(1, 1, 1));
+                        b_inner = 0;
+                    }
                 } else {      // body of ray_color's loop, camera.hpp:944-983
-                    L = L + beta * em;
+                    V3 beta = B.ld3(SF_BETA, slot);
+                    V3 L = mk(0, 0, 0);
+                    bool have_L = false;
+                    if (has_em) { L = B.ld3(SF_L, slot) + beta * em; have_L = true; }
                     bool stop = !sc_ok;
                     if (!stop) {
                         beta = beta * att;
@@ -352,33 +363,38 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                         }
                     }
                     if (!stop) { b_inner++; if (b_inner >= depth_inner) stop = true; }
-                    if (stop) { contrib = att0 * L; ended = true; }
+                    if (stop) {
+                        if (!have_L) L = B.ld3(SF_L, slot);
+                        contrib = B.ld3(SF_ATT0, slot) * L; ended = true;
+                    } else {
+                        if (have_L) B.st3(SF_L, slot, L);
+                        B.st3(SF_BETA, slot, beta);
+                    }
+                }
+                if (!ended) {
+                    // the path continues: publish the scattered ray
+                    B.st3(SF_RAY, slot, nr.o); B.st3(SF_RAY + 3, slot, nr.d);
+                    m.x = (uint32_t)g.k; m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE;
+                    B.st2(SF_MA, slot, m);
+                    active_after = true;
                 }
             }
-            if (!ended) {
-                // the path continues: publish the scattered ray and the path state
-                stnt(B.ray + 0 * P + slot, nr.o.x); stnt(B.ray + 1 * P + slot, nr.o.y); stnt(B.ray + 2 * P + slot, nr.o.z);
-                stnt(B.ray + 3 * P + slot, nr.d.x); stnt(B.ray + 4 * P + slot, nr.d.y); stnt(B.ray + 5 * P + slot, nr.d.z);
-                B.L[slot] = L.x; B.L[P + slot] = L.y; B.L[2 * P + slot] = L.z;
-                B.beta[slot] = beta.x; B.beta[P + slot] = beta.y; B.beta[2 * P + slot] = beta.z;
-                if (cont_first) { B.att0[slot] = att0.x; B.att0[P + slot] = att0.y; B.att0[2 * P + slot] = att0.z; }
-                if (first) { B.sum[slot] = sum.x; B.sum[P + slot] = sum.y; B.sum[2 * P + slot] = sum.z; }
-                m.x = (uint32_t)g.k; m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE;
-                B.meta[slot] = m;
-                active_after = true;
-            } else {
+            if (has_add && !ended) B.st3(SF_SUM, slot, B.ld3(SF_SUM, slot) + add_now);
+            if (ended) {
+                V3 sum = B.ld3(SF_SUM, slot);
+                if (has_add) sum = sum + add_now;
                 sum = sum + contrib;
                 if (COUNT) c_draws += g.k;
                 // next sample of this unit, or a new unit
-                uint32_t sample = m.w + B.lanes;
+                const uint32_t sample = mb.y + B.lanes;
                 if (sample < (uint32_t)cam.spp) {
-                    B.sum[slot] = sum.x; B.sum[P + slot] = sum.y; B.sum[2 * P + slot] = sum.z;
-                    begin_sample(B, cam, seed, slot, m.z, sample, c_samp);
+                    B.st3(SF_SUM, slot, sum);
+                    begin_sample(B, cam, seed, slot, mb.x, sample, c_samp);
                     active_after = true;
                 } else {
-                    double* pp = B.partial + (size_t)m.z * 3;  // = [pixel][lane][3]
+                    double* pp = B.partial + (size_t)mb.x * 3;  // = [pixel][lane][3]
                     pp[0] = sum.x; pp[1] = sum.y; pp[2] = sum.z;
-                    B.sum[slot] = 0.0; B.sum[P + slot] = 0.0; B.sum[2 * P + slot] = 0.0;
+                    B.st3(SF_SUM, slot, mk(0, 0, 0));
                     want_unit = true;
                 }
             }
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
                 const unsigned long long u = (unsigned long long)B.P + k * ST_SHARDS + shard;
                 if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, (uint32_t)(u % B.lanes), c_samp); active_after = true; }
-                else { uint4 m0; m0.x = 0; m0.y = 0; m0.z = 0; m0.w = 0; B.meta[slot] = m0; }
+                else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
             }
         }
     }
@@ -437,24 +453,12 @@ int stream_extend_blocks() {
 }
 
 // layout of the slot pool inside one allocation; returns bytes needed
-size_t stream_pool_bytes(uint32_t P) {
-    return (size_t)P * (6 * 8 + 8 + 8 + 4 * 3 * 8 + 8 + 16) + 4096;
-}
+size_t stream_pool_bytes(uint32_t P) { return ((size_t)(P + 63) / 64) * SF_N * 64 * sizeof(double); }
 
 static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t n_units, uint32_t n_pix, const uint32_t* pixels, double* partial,
                           unsigned int* ctl) {
     StreamBuf B;
-    unsigned char* p = (unsigned char*)pool;
-    B.ray = (double*)p; p += (size_t)P * 48;
-    B.hit_t = (double*)p; p += (size_t)P * 8;
-    B.hit_ki = (uint2*)p; p += (size_t)P * 8;
-    B.beta = (double*)p; p += (size_t)P * 24;
-    B.L = (double*)p; p += (size_t)P * 24;
-    B.att0 = (double*)p; p += (size_t)P * 24;
-    B.sum = (double*)p; p += (size_t)P * 24;
-    B.key = (unsigned long long*)p; p += (size_t)P * 8;
-    B.meta = (uint4*)p;
-    B.pixels = pixels; B.partial = partial; B.ctl = ctl;
+    B.pool = (double*)pool; B.pixels = pixels; B.partial = partial; B.ctl = ctl;
     B.P = P; B.lanes = lanes; B.n_units = n_units; B.n_pix = n_pix;
     return B;
 }
@@ -474,7 +478,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     if (timer) timer->end(stream, 0);
     *h_active = 1;
     int rounds = 0;
-    const int check_every = 8;
+    int check_every = 8;
     const int eb = (int)((P + 63) / 64 < (uint32_t)extend_blocks ? (P + 63) / 64 : (uint32_t)extend_blocks);
     bool cancelled = false;
     for (;;) {
@@ -492,6 +496,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         if ((e = hipMemcpyAsync(h_active, d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
         if (*h_active == 0) break;
+        check_every = *h_active > P / 2 ? 8 : (*h_active > P / 16 ? 4 : 2);
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }
