@@ -33,7 +33,7 @@ WORKLOADS = {
     "cfg1": ("cfg1", (), "3 Lambertian spheres, 400x225, 16 spp, depth 8"),
 }
 # bounded CPU-baseline samples (zenith_ref `time` arguments: xstep ystep spp), sized for ~10-30 s on 16 host threads
-CPU_SAMPLE = {"cfg3": (8, 8, 16), "cfg2": (4, 4, 8), "cfg5": (4, 4, 16), "cfg1": (1, 1, 16)}
+CPU_SAMPLE = {"cfg3": (4, 4, 128), "cfg2": (4, 4, 48), "cfg5": (4, 4, 48), "cfg1": (1, 1, 16)}
 
 
 def cpu_baseline(workload, threads):
@@ -115,7 +115,10 @@ def main():
     step(count=True)
     torch.cuda.synchronize(dev)
     ctr = ctx.counters()
-    seg_local, bytes_local = ctr.segments, ctr.algorithmic_bytes()
+    seg_local = ctr.segments
+    # the dominant kernel of the streaming pipeline is EXTEND (BVH walk): it owns the box / primitive bytes; the 76 B of
+    # shading data per hit belong to the SHADE kernel and are left out of the EXTEND roofline
+    bytes_local = ctr.algorithmic_bytes() - (76 * ctr.hits if int(os.environ.get("ZR_KERNEL", "2")) == 2 else 0)
     tot = torch.tensor([seg_local, bytes_local, ctr.primary_samples], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tot)
@@ -135,14 +138,17 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
-    launches = ctx.kernel_times_ms(4096)  # HIP events on the launch stream, timed steps only
+    launches = ctx.kernel_times_ms(1 << 20)  # dominant kernel's launches (HIP events on the launch stream), timed steps only
+    variant = int(os.environ.get("ZR_KERNEL", "2"))
+    kernel_name = {0: "render_pixels", 1: "render_wavefront", 2: "stream_extend"}.get(variant, "?")
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = segments * args.steps / dt * 1e-6
         k_ms = sum(launches) / max(1, len(launches))
         launches_per_step = max(1, len(launches) // max(1, args.steps))
-        # roofline of the dominant (only) kernel: this rank's algorithmic bytes per launch / mean launch duration
+        # roofline of the dominant kernel: this rank's algorithmic bytes per launch / mean launch duration
+        # (= bytes of one step / summed duration of that kernel's launches in one step)
         achieved = (bytes_local / launches_per_step) / (k_ms * 1e-3) * 1e-9 if k_ms > 0 else 0.0
         out = {
             "metric": "Msamples/sec (rays·bounces)", "value": round(value, 3), "unit": "Msamples/s",
@@ -157,7 +163,8 @@ def main():
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "render_pixels", "kernel_ms": round(k_ms, 4), "launches_timed": len(launches),
+                         "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "launches_timed": len(launches),
+                         "kernel_ms_per_step": round(sum(launches) / max(1, args.steps), 3),
                          "algorithmic_bytes_per_launch": int(bytes_local / launches_per_step),
                          "model": "32 B/child box tested + 72 B/triangle + 32 B/sphere + 48 B/cube + 76 B/hit (SURVEY §8d)"},
         }

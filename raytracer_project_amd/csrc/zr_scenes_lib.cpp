@@ -72,3 +72,21 @@ int zrs_render_dropin(void* p, int width, int height, int spp, int device, doubl
 }
 
 }  // extern "C"
+
+// sizes of the ABI structs as the C++ compiler sees them (tests compare them with the ctypes mirrors)
+extern "C" size_t zrs_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(zr_xform_op);
+        case 1: return sizeof(zr_object);
+        case 2: return sizeof(zr_medium);
+        case 3: return sizeof(zr_material);
+        case 4: return sizeof(zr_texture);
+        case 5: return sizeof(zr_env);
+        case 6: return sizeof(zr_camera);
+        case 7: return sizeof(zr_region);
+        case 8: return sizeof(zr_counters);
+        case 9: return sizeof(zr_hit);
+        case 10: return sizeof(zr_scene_desc);
+        default: return 0;
+    }
+}
