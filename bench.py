@@ -150,6 +150,13 @@ def main():
         # roofline of the dominant kernel: this rank's algorithmic bytes per launch / mean launch duration
         # (= bytes of one step / summed duration of that kernel's launches in one step)
         achieved = (bytes_local / launches_per_step) / (k_ms * 1e-3) * 1e-9 if k_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel from the committed FETCH_SIZE pass (separate --pmc run)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_v2_cfg3_traffic.json")))
+            if tj["workload"] == args.workload and world == 1 and args.spp == 0:
+                traffic = int(tj["kernels"][kernel_name]["hbm_read_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "Msamples/sec (rays·bounces)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -162,7 +169,7 @@ def main():
                        "scene_build_s": round(t_scene, 3), "bvh_build_upload_s": round(t_commit, 3),
                        "frame_checksum": checksum},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "launches_timed": len(launches),
                          "kernel_ms_per_step": round(sum(launches) / max(1, args.steps), 3),
                          "algorithmic_bytes_per_launch": int(bytes_local / launches_per_step),
