@@ -383,7 +383,7 @@ zr_ctx* zr_create(int device_ordinal) {
         c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 16.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
         if (c->d_ctl.alloc(zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
-            hipHostMalloc((void**)&c->h_active, 64, 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
+            hipHostMalloc((void**)&c->h_active, zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
     if (c->variant == 1) {
         c->wf_blocks = zr::wavefront_max_blocks();

@@ -51,9 +51,9 @@ struct StreamBuf {
     double* pool;             // [P / 64][SF_N][64] 8-byte cells
     const uint32_t* pixels;   // [n_pix] px | py << 16
     double* partial;          // [n_pix][lanes][3]
-    unsigned int* ctl;        // [1] active slots after the last SHADE, [2] iteration-cap hits; per shard s: [16 + 32 s] unit counter,
-                              // [16 + 32 s + 8] EXTEND chunk head (ST_SHARDS words on separate cache lines: a single
-                              // contended word sustains only ~90 atomics/us)
+    unsigned int* ctl;        // [2] iteration-cap hits; per shard s: [16 + 32 s] unit counter, [16 + 32 s + 8] EXTEND chunk head,
+                              // [16 + 32 s + 16] active slots after the last SHADE (ST_SHARDS words on separate cache lines:
+                              // a single contended word sustains only ~90 atomics/us)
     uint32_t P, lanes, n_units, n_pix;
     __device__ __forceinline__ double* cell(int f, uint32_t slot) const { return pool + ((size_t)(slot >> 6) * SF_N + f) * 64 + (slot & 63u); }
     __device__ __forceinline__ double ld(int f, uint32_t slot) const { return *cell(f, slot); }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
     bool work_left = true;
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the private range of ray indices being handed out
     uint32_t head_shard = blockIdx.x % ST_SHARDS, shards_tried = 0;
-    if (blockIdx.x == 0 && lane == 0) B.ctl[1] = 0;  // SHADE of this round recounts the active slots
+    if (blockIdx.x == 0 && lane < ST_SHARDS) B.ctl[16 + 32 * lane + 16] = 0;  // SHADE of this round recounts the active slots
     uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_cube = 0, c_med = 0, c_seg = 0, c_hits = 0;
     unsigned long long s_exec[2] = {0, 0}, s_lanes[2] = {0, 0};
 
@@ -417,8 +417,10 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             }
         }
     }
+    // active-slot count for the host's round loop: sharded like the other counters — one contended word would cost
+    // ~3 ms per 16 M-slot round (262 144 wave atomics at ~90 per microsecond)
     const unsigned long long am = __ballot(active_after);
-    if ((threadIdx.x & 63) == 0 && am != 0ull) atomicAdd(&B.ctl[1], (unsigned int)__popcll(am));
+    if ((threadIdx.x & 63) == 0 && am != 0ull) atomicAdd(&B.ctl[16 + 32 * (blockIdx.x % ST_SHARDS) + 16], (unsigned int)__popcll(am));
     if (COUNT) {
         if (c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
         if (c_draws) atomicAdd(&gctr[8], c_draws);
@@ -476,7 +478,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     if (count) hipLaunchKernelGGL(stream_init<true>, dim3(pblocks), dim3(256), 0, stream, B, cam, seed, gctr);
     else hipLaunchKernelGGL(stream_init<false>, dim3(pblocks), dim3(256), 0, stream, B, cam, seed, gctr);
     if (timer) timer->end(stream, 0);
-    *h_active = 1;
+    h_active[0] = 1;
     int rounds = 0;
     int check_every = 8;
     const int eb = (int)((P + 63) / 64 < (uint32_t)extend_blocks ? (P + 63) / 64 : (uint32_t)extend_blocks);
@@ -493,10 +495,12 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
             if (timer) timer->end(stream, 2);
             rounds++;
         }
-        if ((e = hipMemcpyAsync(h_active, d_ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(h_active, d_ctl, stream_ctl_words() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
-        if (*h_active == 0) break;
-        check_every = *h_active > P / 2 ? 8 : (*h_active > P / 16 ? 4 : 2);
+        unsigned long long active = 0;
+        for (int sh = 0; sh < ST_SHARDS; sh++) active += h_active[16 + 32 * sh + 16];
+        if (active == 0) break;
+        check_every = active > P / 2 ? 8 : (active > P / 16 ? 4 : 2);
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }
