@@ -134,6 +134,7 @@ struct zr_scene {
     DevBuf<zr_texture> d_texs;
     DevBuf<unsigned char> d_texels;
     zr::DScene ds{};
+    bool generic_leaves = true;   // the BVH has leaves other than bare triangles / spheres
     uint64_t stats[4] = {0, 0, 0, 0};
 };
 
@@ -380,7 +381,7 @@ zr_ctx* zr_create(int device_ordinal) {
         c->st_blocks = zr::stream_extend_blocks();
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
         if (over > 0) c->st_blocks = over;
-        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 16.0 * 1024 * 1024);
+        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
         if (c->d_ctl.alloc(zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
             hipHostMalloc((void**)&c->h_active, zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
@@ -569,6 +570,7 @@ int zr_scene_commit(zr_scene* s) {
     d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
     d.n_mats = (uint32_t)s->materials.size();
     d.root_meta = 0;
+    s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
     s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
     s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_n.size() + fl.cubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.tri_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
@@ -730,7 +732,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     HostTimer timer(c);
     int rounds = 0;
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, lanes, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
-                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, &timer, c->h_active, keep_going, &rounds);
+                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, &timer, c->h_active, keep_going, &rounds, s->generic_leaves);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     unsigned int ctl[4] = {0, 0, 0, 0};

@@ -32,6 +32,9 @@ namespace zr {
 #ifndef ST_SHADE_WAVES
 #define ST_SHADE_WAVES 2 /* 256-thread blocks per CU (= waves per SIMD) the SHADE kernel must fit */
 #endif
+#ifndef ST_EXT_WAVES_LEAN
+#define ST_EXT_WAVES_LEAN 6  /* same for the triangles-and-spheres-only build of EXTEND */
+#endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #define ST_LDS_STACK 8
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
@@ -94,8 +97,10 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 // ---- EXTEND: closest hit for every active slot ------------------------------------------------------------
 enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2, X_EXIT = 3 };
 
-template <bool COUNT>
-__global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
+// GENERIC = false: the world holds only bare triangles and spheres (no cubes, media or wrapped objects), so the
+// code for those leaf kinds — and the registers it needs — is compiled out (cfg2, cfg3).
+template <bool COUNT, bool GENERIC>
+__global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
                                                                   unsigned long long* __restrict__ gctr) {
     __shared__ SEntry lstack[ST_LDS_STACK * 64];
     const int lane = threadIdx.x;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
                     if (m.y & F_ACTIVE) {
                         slot = my;
                         ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
-                        g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu;
+                        if (GENERIC) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
                         idx_ = 1.0 / ray.d.x; idy_ = 1.0 / ray.d.y; idz_ = 1.0 / ray.d.z;
                         ox_ = ray.o.x * idx_; oy_ = ray.o.y * idy_; oz_ = ray.o.z * idz_;
                         tbest = INF; kbest = NONE; cur = 0; sp = 0; pa_meta = 0; pb_meta = 0; pend_i = 0;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64, ST_EXT_WAVES) void stream_extend(DScene sc, Str
                     if (sphere_t(sc.spheres + (size_t)(pa_first + pend_i) * 4, ray, 0.001, tbest, t)) { tbest = t; kbest = lkind; ibest = pa_first + pend_i; }
                     tested = true;
                 }
-            } else if (is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+            } else if (GENERIC && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
                 if (COUNT) {
                     uint32_t kk = lkind;
@@ -450,7 +455,9 @@ int stream_extend_blocks() {
         hipDeviceProp_t p;
         if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+    int lean = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false, true>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lean, stream_extend<false, false>, 64, 0) == hipSuccess && lean > per_cu) per_cu = lean;
     return cus * per_cu;
 }
 
@@ -468,7 +475,7 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t n_uni
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t lanes,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_partial, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t stream, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out) {
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic) {
     const uint32_t n_units = n_pix * lanes;
     StreamBuf B = make_buf(pool, P, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl);
     hipError_t e;
@@ -486,8 +493,13 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     for (;;) {
         for (int k = 0; k < check_every; k++) {
             if (timer) timer->begin(stream, 1);
-            if (count) hipLaunchKernelGGL(stream_extend<true>, dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
-            else hipLaunchKernelGGL(stream_extend<false>, dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
+            if (generic) {
+                if (count) hipLaunchKernelGGL((stream_extend<true, true>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
+                else hipLaunchKernelGGL((stream_extend<false, true>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
+            } else {
+                if (count) hipLaunchKernelGGL((stream_extend<true, false>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
+                else hipLaunchKernelGGL((stream_extend<false, false>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
+            }
             if (timer) timer->end(stream, 1);
             if (timer) timer->begin(stream, 2);
             if (count) hipLaunchKernelGGL(stream_shade<true>, dim3(pblocks), dim3(256), 0, stream, sc, cam, env, seed, B, gctr);
