@@ -20,6 +20,15 @@ struct alignas(64) NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
+// 4-wide node (128 B = one L2 line): the children's FP32 boxes as six float4 rows + links + leaf meta.  Walked by
+// the EXTEND kernel of variant 2: half as many dependent fetches per ray as the pair records, one line each.
+struct alignas(128) NodeQuad {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t child[4];  // as NodePair::child
+    uint32_t meta[4];   // as NodePair::meta; an unused slot is a leaf with count 0
+};
+static_assert(sizeof(NodeQuad) == 128, "NodeQuad must be 128 bytes");
+
 struct DMedium {
     uint32_t btype, bindex, chain_first, chain_count;
     uint32_t mat, id;
@@ -29,6 +38,7 @@ struct DWrapped { uint32_t type, index, chain_first, chain_count; };
 
 struct DScene {
     const NodePair* nodes;
+    const NodeQuad* quads;
     const double* spheres;      // 4 per sphere: cx cy cz max(0, r)
     const uint32_t* sphere_mat;
     const double* tri_v;        // 9 per triangle

@@ -125,6 +125,8 @@ struct zr_scene {
     // device
     bool committed = false;
     DevBuf<zr::NodePair> d_nodes;
+    DevBuf<zr::NodeQuad> d_quads;
+    bool quad_ok = true;          // leaf references fit the EXTEND kernel's 32-bit stack entries
     DevBuf<double> d_spheres, d_tri_v, d_tri_n, d_cubes;
     DevBuf<uint32_t> d_sphere_mat, d_tri_mat, d_cube_mat;
     DevBuf<zr::DMedium> d_media;
@@ -257,6 +259,9 @@ struct Flattener {
     const std::vector<zr_object>& objs;
     const zr::BuildResult& br;
     std::vector<zr::NodePair> pairs;
+    std::vector<zr::NodeQuad> quads;
+    std::vector<uint32_t> leaf_first;  // per build node: device index of a leaf's first primitive
+    int quad_depth = 0;
     std::vector<double> spheres, tri_v, tri_n, cubes;
     std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
     std::vector<zr::DMedium> media;
@@ -318,6 +323,7 @@ struct Flattener {
         for (int k = 0; k < 3; k++) { pairs[pair].lo[slot][k] = f_down(n.box.lo[k]); pairs[pair].hi[slot][k] = f_up(n.box.hi[k]); }
         if (n.count) {
             uint32_t first = append_leaf(n);
+            leaf_first[node_id] = first;
             pairs[pair].child[slot] = first;
             pairs[pair].meta[slot] = ((n.kind + 1u) << 16) | n.count;
         } else {
@@ -339,15 +345,56 @@ struct Flattener {
         pairs[pair].child[slot] = 0;
         pairs[pair].meta[slot] = (1u << 16) | 0u;  // leaf with zero primitives
     }
+    // ---- 4-wide nodes: collapse of the binary tree (largest-area internal child is opened first) ----
+    static double area(const zr::BuildBox& b) {
+        double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    void quad_empty(uint32_t q, int slot) {
+        quads[q].lox[slot] = quads[q].loy[slot] = quads[q].loz[slot] = 0.f;
+        quads[q].hix[slot] = quads[q].hiy[slot] = quads[q].hiz[slot] = 0.f;
+        quads[q].child[slot] = 0; quads[q].meta[slot] = (1u << 16) | 0u;
+    }
+    void quad_child(uint32_t q, int slot, int32_t node_id, int depth) {
+        const zr::BuildNode& n = br.nodes[node_id];
+        quads[q].lox[slot] = f_down(n.box.lo[0]); quads[q].loy[slot] = f_down(n.box.lo[1]); quads[q].loz[slot] = f_down(n.box.lo[2]);
+        quads[q].hix[slot] = f_up(n.box.hi[0]); quads[q].hiy[slot] = f_up(n.box.hi[1]); quads[q].hiz[slot] = f_up(n.box.hi[2]);
+        if (n.count) { quads[q].child[slot] = leaf_first[node_id]; quads[q].meta[slot] = ((n.kind + 1u) << 16) | n.count; }
+        else { uint32_t c = emit_quad(node_id, depth + 1); quads[q].child[slot] = c; quads[q].meta[slot] = 0; }
+    }
+    uint32_t emit_quad(int32_t node_id, int depth) {
+        uint32_t q = (uint32_t)quads.size();
+        quads.push_back(zr::NodeQuad{});
+        quad_depth = std::max(quad_depth, depth);
+        int32_t kids[4]; int nk = 2;
+        kids[0] = br.nodes[node_id].left; kids[1] = br.nodes[node_id].right;
+        while (nk < 4) {
+            int best = -1; double ba = -1;
+            for (int k = 0; k < nk; k++) if (br.nodes[kids[k]].count == 0 && area(br.nodes[kids[k]].box) > ba) { ba = area(br.nodes[kids[k]].box); best = k; }
+            if (best < 0) break;
+            int32_t open = kids[best];
+            kids[best] = br.nodes[open].left; kids[nk++] = br.nodes[open].right;
+        }
+        for (int k = 0; k < 4; k++) { if (k < nk) quad_child(q, k, kids[k], depth); else quad_empty(q, k); }
+        return q;
+    }
     void run() {
-        if (br.nodes.empty()) { pairs.push_back(zr::NodePair{}); empty_child(0, 0); empty_child(0, 1); return; }
+        leaf_first.assign(br.nodes.size(), 0);
+        if (br.nodes.empty()) {
+            pairs.push_back(zr::NodePair{}); empty_child(0, 0); empty_child(0, 1);
+            quads.push_back(zr::NodeQuad{}); for (int k = 0; k < 4; k++) quad_empty(0, k);
+            return;
+        }
         if (br.nodes[0].count) {  // the whole world fits one leaf
             pairs.push_back(zr::NodePair{});
             set_child(0, 0, 0);
             empty_child(0, 1);
+            quads.push_back(zr::NodeQuad{});
+            quad_child(0, 0, 0, 0); for (int k = 1; k < 4; k++) quad_empty(0, k);
             return;
         }
         emit_pair(0);
+        emit_quad(0, 0);
     }
 };
 
@@ -530,6 +577,9 @@ int zr_scene_commit(zr_scene* s) {
     fl.run();
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
+    if ((rc = s->d_quads.upload(fl.quads))) return rc;
+    s->quad_ok = max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_mat.size() < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
+                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24);
     if ((rc = s->d_spheres.upload(fl.spheres))) return rc;
     if ((rc = s->d_sphere_mat.upload(fl.sphere_mat))) return rc;
     if ((rc = s->d_tri_v.upload(fl.tri_v))) return rc;
@@ -562,7 +612,7 @@ int zr_scene_commit(zr_scene* s) {
     if ((rc = s->d_texels.upload(s->texels))) return rc;
 
     zr::DScene& d = s->ds;
-    d.nodes = s->d_nodes.p;
+    d.nodes = s->d_nodes.p; d.quads = s->d_quads.p;
     d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
     d.tri_v = s->d_tri_v.p; d.tri_n = s->d_tri_n.p; d.tri_mat = s->d_tri_mat.p;
     d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
@@ -572,7 +622,7 @@ int zr_scene_commit(zr_scene* s) {
     d.root_meta = 0;
     s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
     s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
-    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_n.size() + fl.cubes.size()) * 8 +
+    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQuad) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_n.size() + fl.cubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.tri_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
     s->committed = true;
     return ZR_OK;
@@ -755,6 +805,8 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
     HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    if (c->variant == 2 && dc.max_depth <= 250 && !s->quad_ok)
+        return fail(ZR_E_INVALID, "kernel variant 2 needs < 16 Mi primitives per kind and leaves of <= 16 primitives; set ZR_KERNEL=1");
     if (c->variant == 2 && dc.max_depth <= 250) {
         int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going);
         if (rows_done && r2 == ZR_OK) *rows_done = plan.H;

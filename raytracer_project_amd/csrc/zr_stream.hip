@@ -36,7 +36,7 @@ namespace zr {
 #define ST_EXT_WAVES_LEAN 6  /* same for the triangles-and-spheres-only build of EXTEND */
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
-#define ST_LDS_STACK 8
+#define ST_LDS_STACK 12
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
 enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17 };  // meta.y: bounce | b_inner << 8 | flags
@@ -95,7 +95,21 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 }
 
 // ---- EXTEND: closest hit for every active slot ------------------------------------------------------------
-enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2, X_EXIT = 3 };
+// Walks the 4-wide tree (NodeQuad, 128 B = one L2 line per step).  Box tests are FP32 and CONSERVATIVE: with
+// o = o_hi + o_lo (+ <= 2^-48 |o|), t = ((b - o_hi) - o_lo) * id carries a relative error below 2^-21 (two
+// subtractions, the product, the rounding of 1/d to float), so the entry distance is lowered and the exit distance
+// raised by |t| * 2^-20 plus an absolute slack c_ray for the dropped origin bits.  A superset of box hits cannot change
+// the closest primitive; every primitive test stays FP64.  A NaN slab (0 * inf) is ignored by fminf/fmaxf, which
+// keeps the box (conservative).
+enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2 };
+#define X_LEAF_BIT 0x80000000u
+
+__device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32_t& rb) {
+    const bool sw = tb < ta;
+    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
+    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ta = t0; tb = t1; ra = r0; rb = r1;
+}
 
 // GENERIC = false: the world holds only bare triangles and spheres (no cubes, media or wrapped objects), so the
 // code for those leaf kinds — and the registers it needs — is compiled out (cfg2, cfg3).
@@ -107,15 +121,19 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     SEntry* gstack = overflow + (size_t)blockIdx.x * ST_OVERFLOW * 64 + lane;
     const double INF = __builtin_huge_val();
+    const float INFf = __builtin_huge_valf();
     const uint32_t NONE = 0xFFFFFFFFu;
+
     int st = X_IDLE;
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
-    double idx_ = 0, idy_ = 0, idz_ = 0, ox_ = 0, oy_ = 0, oz_ = 0;
+    float ohx = 0, ohy = 0, ohz = 0, olx = 0, oly = 0, olz = 0, idx_ = 0, idy_ = 0, idz_ = 0, c_ray = 0;
     double tbest = INF;
-    uint32_t kbest = NONE, ibest = 0, cur = NONE;
+    float tbest_f = INFf;
+    uint32_t kbest = NONE, ibest = 0;
+    uint32_t cur = 0;       // X_NODE: quad index; X_LEAF: leaf reference (kind << 28 | (count - 1) << 24 | first)
+    uint32_t pend_i = 0;
     int sp = 0;
-    uint32_t pa_first = 0, pa_meta = 0, pb_first = 0, pb_meta = 0, pend_i = 0;
     Rng g; g.key = 0; g.k = 0; g.bounce = 0;  // only the medium test reads it
     bool work_left = true;
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the private range of ray indices being handed out
@@ -124,14 +142,6 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_cube = 0, c_med = 0, c_seg = 0, c_hits = 0;
     unsigned long long s_exec[2] = {0, 0}, s_lanes[2] = {0, 0};
 
-    auto pop_next = [&]() {
-        cur = NONE;
-        while (sp > 0) {
-            sp--;
-            SEntry e = sp < ST_LDS_STACK ? lstack[sp * 64 + lane] : gstack[(size_t)(sp - ST_LDS_STACK) * 64];
-            if ((double)e.tn <= tbest) { cur = e.node; break; }
-        }
-    };
     auto finish = [&]() {  // traversal of this lane's ray is complete: publish the result
         B.st(SF_HIT_T, slot, tbest);
         uint2 ki; ki.x = kbest; ki.y = ibest;
@@ -139,23 +149,39 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         if (COUNT && kbest != NONE) c_hits++;
         st = X_IDLE;
     };
+// stack helpers are macros, not lambdas: a lambda capturing the __shared__ array by reference turns its accesses into
+// flat-pointer accesses (and trips an LLVM verifier error on gfx950)
+#define ZR_PUSH(REF, TN)                                                                                        \
+    {                                                                                                           \
+        SEntry e_; e_.node = (REF); e_.tn = (TN);                                                               \
+        if (sp < ST_LDS_STACK) lstack[sp * 64 + lane] = e_; else gstack[(size_t)(sp - ST_LDS_STACK) * 64] = e_; \
+        sp++;                                                                                                   \
+    }
+// nearest deferred entry that can still matter, else the ray is done
+#define ZR_POP_NEXT()                                                                                           \
+    for (;;) {                                                                                                  \
+        if (sp == 0) { finish(); break; }                                                                       \
+        sp--;                                                                                                   \
+        SEntry e_;                                                                                              \
+        if (sp < ST_LDS_STACK) e_ = lstack[sp * 64 + lane]; else e_ = gstack[(size_t)(sp - ST_LDS_STACK) * 64]; \
+        if (e_.tn <= tbest_f) { cur = e_.node; pend_i = 0; st = (e_.node & X_LEAF_BIT) ? X_LEAF : X_NODE; break; } \
+    }
 
     const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
     unsigned long long iter = 0;
     for (; iter < iter_cap; iter++) {
-        const uint32_t lkind = (pa_meta >> 16) - 1u;
+        const uint32_t lkind = (cur >> 28) & 7u;
         const int n1 = __popcll(__ballot(st == X_NODE));
         const int n2t = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_TRIANGLE));
         const int n2s = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_SPHERE));
-        const int n2g = __popcll(__ballot(st == X_LEAF)) - n2t - n2s;
+        const int n2g = GENERIC ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
         const int n0 = work_left ? __popcll(__ballot(st == X_IDLE)) : 0;
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
         if (n1 + n2 + n0 == 0) break;
 
         if (n0 >= 16 || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
             // ================= FETCH: idle lanes take the next ray indices =================
-            // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays (a single
-            // contended word sustains only ~90 atomics/us on this chip)
+            // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays
             const unsigned long long idle = __ballot(st == X_IDLE);
             uint32_t n = (uint32_t)__popcll(idle);
             while (chunk_next >= chunk_end && work_left) {
@@ -185,69 +211,56 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
                         slot = my;
                         ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
                         if (GENERIC) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
-                        idx_ = 1.0 / ray.d.x; idy_ = 1.0 / ray.d.y; idz_ = 1.0 / ray.d.z;
-                        ox_ = ray.o.x * idx_; oy_ = ray.o.y * idy_; oz_ = ray.o.z * idz_;
-                        tbest = INF; kbest = NONE; cur = 0; sp = 0; pa_meta = 0; pb_meta = 0; pend_i = 0;
+                        ohx = (float)ray.o.x; ohy = (float)ray.o.y; ohz = (float)ray.o.z;
+                        olx = (float)(ray.o.x - (double)ohx); oly = (float)(ray.o.y - (double)ohy); olz = (float)(ray.o.z - (double)ohz);
+                        idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
+                        const float mo = fmaxf(fmaxf(fabsf(ohx), fabsf(ohy)), fabsf(ohz));
+                        const float mi = fmaxf(fmaxf(fabsf(idx_), fabsf(idy_)), fabsf(idz_));
+                        c_ray = mo * mi * 2.8421709e-14f;  // 2^-45: the origin bits beyond o_hi + o_lo, with slack
+                        if (!(c_ray < INFf)) c_ray = 0.0f;  // a zero direction component: that slab is +-inf / NaN anyway
+                        tbest = INF; tbest_f = INFf; kbest = NONE; cur = 0; sp = 0; pend_i = 0;
                         st = X_NODE;
                         if (COUNT) c_seg++;
                     }
                 }
             }
         } else if (n1 >= n2) {
-            // ================= NODE: one sibling-pair record per lane =================
+            // ================= NODE: one 4-wide node per lane =================
             if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
             if (st == X_NODE) {
-                const NodePair* np = sc.nodes + cur;
-                const float4 q0 = reinterpret_cast<const float4*>(np)[0];
-                const float4 q1 = reinterpret_cast<const float4*>(np)[1];
-                const float4 q2 = reinterpret_cast<const float4*>(np)[2];
-                const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
-                if (COUNT) c_nodes += 2;
-                double tn0, tf0, tn1, tf1;
-                {
-                    double a0 = fma((double)q0.x, idx_, -ox_), a1 = fma((double)q1.z, idx_, -ox_);
-                    double b0 = fma((double)q0.y, idy_, -oy_), b1 = fma((double)q1.w, idy_, -oy_);
-                    double c0 = fma((double)q0.z, idz_, -oz_), c1 = fma((double)q2.x, idz_, -oz_);
-                    tn0 = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), 0.001));
-                    tf0 = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
-                }
-                {
-                    double a0 = fma((double)q0.w, idx_, -ox_), a1 = fma((double)q2.y, idx_, -ox_);
-                    double b0 = fma((double)q1.x, idy_, -oy_), b1 = fma((double)q2.z, idy_, -oy_);
-                    double c0 = fma((double)q1.y, idz_, -oz_), c1 = fma((double)q2.w, idz_, -oz_);
-                    tn1 = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), 0.001));
-                    tf1 = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
-                }
-                bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-                if (q3.z != 0 && (q3.z & 0xFFFFu) == 0) h0 = false;
-                if (q3.w != 0 && (q3.w & 0xFFFFu) == 0) h1 = false;
-                const bool swp = h0 && h1 && tn1 < tn0;
-                const uint32_t cA = swp ? q3.y : q3.x, cB = swp ? q3.x : q3.y;
-                const uint32_t mA = swp ? q3.w : q3.z, mB = swp ? q3.z : q3.w;
-                const bool hA = swp ? h1 : h0, hB = swp ? h0 : h1;
-                const double tnB = swp ? tn0 : tn1;
-                uint32_t next = NONE;
-                pa_meta = 0; pb_meta = 0; pend_i = 0;
-                if (hA) {
-                    if (mA != 0) { pa_first = cA; pa_meta = mA; } else next = cA;
-                }
-                if (hB) {
-                    if (mB != 0) {
-                        if (pa_meta == 0) { pa_first = cB; pa_meta = mB; } else { pb_first = cB; pb_meta = mB; }
-                    } else if (next == NONE) {
-                        next = cB;
-                    } else {
-                        SEntry e; e.node = cB; e.tn = __double2float_rd(tnB);
-                        if (sp < ST_LDS_STACK) lstack[sp * 64 + lane] = e; else gstack[(size_t)(sp - ST_LDS_STACK) * 64] = e;
-                        sp++;
-                    }
-                }
-                cur = next;
-                if (pa_meta != 0) st = X_LEAF;
-                else {
-                    if (cur == NONE) pop_next();
-                    if (cur == NONE) finish();
-                }
+                const float4* nq = reinterpret_cast<const float4*>(sc.quads + cur);
+                const float4 lx = nq[0], ly = nq[1], lz = nq[2], hx = nq[3], hy = nq[4], hz = nq[5];
+                const uint4 ch = reinterpret_cast<const uint4*>(nq)[6];
+                const uint4 me = reinterpret_cast<const uint4*>(nq)[7];
+                float tn0, tn1, tn2, tn3;
+                uint32_t r0, r1, r2, r3;
+#define ZR_BOX(LX, LY, LZ, HX, HY, HZ, CH, ME, TN, RF)                                                        \
+    {                                                                                                       \
+        const float x0 = (((LX) - ohx) - olx) * idx_, x1 = (((HX) - ohx) - olx) * idx_;                     \
+        const float y0 = (((LY) - ohy) - oly) * idy_, y1 = (((HY) - ohy) - oly) * idy_;                     \
+        const float z0 = (((LZ) - ohz) - olz) * idz_, z1 = (((HZ) - ohz) - olz) * idz_;                     \
+        float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.000999f));            \
+        float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest_f));              \
+        n_ = n_ - (fabsf(n_) * 9.5367432e-7f + c_ray);                                                      \
+        f_ = f_ + (fabsf(f_) * 9.5367432e-7f + c_ray);                                                      \
+        const bool empty_ = (ME) != 0u && ((ME) & 0xFFFFu) == 0u;                                           \
+        const bool hit_ = (n_ <= f_) && !empty_;                                                            \
+        if (COUNT && !empty_) c_nodes++;                                                                    \
+        TN = hit_ ? n_ : INFf;                                                                              \
+        RF = (ME) == 0u ? (CH) : (X_LEAF_BIT | ((((ME) >> 16) - 1u) << 28) | ((((ME) & 0xFFFFu) - 1u) << 24) | (CH)); \
+    }
+                ZR_BOX(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, ch.x, me.x, tn0, r0)
+                ZR_BOX(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, ch.y, me.y, tn1, r1)
+                ZR_BOX(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, ch.z, me.z, tn2, r2)
+                ZR_BOX(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, ch.w, me.w, tn3, r3)
+#undef ZR_BOX
+                // sort by entry distance (5-comparator network), push far -> near, continue with the nearest
+                cswap(tn0, r0, tn1, r1); cswap(tn2, r2, tn3, r3); cswap(tn0, r0, tn2, r2); cswap(tn1, r1, tn3, r3); cswap(tn1, r1, tn2, r2);
+                if (tn3 < INFf) ZR_PUSH(r3, tn3)
+                if (tn2 < INFf) ZR_PUSH(r2, tn2)
+                if (tn1 < INFf) ZR_PUSH(r1, tn1)
+                if (tn0 < INFf) { cur = r0; pend_i = 0; st = (r0 & X_LEAF_BIT) ? X_LEAF : X_NODE; }
+                else { ZR_POP_NEXT() }
             }
         } else {
             // ================= LEAF: one primitive per lane, the kind with most waiting lanes =================
@@ -255,40 +268,35 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             const bool is_leaf = st == X_LEAF;
             const bool do_tri = n2t == n2;
             const bool do_sph = !do_tri && n2s == n2;
+            const uint32_t prim = (cur & 0xFFFFFFu) + pend_i;
             bool tested = false;
             if (do_tri) {
                 if (is_leaf && lkind == ZR_PRIM_TRIANGLE) {
                     double t;
                     if (COUNT) c_tri++;
-                    if (triangle_t(sc.tri_v + (size_t)(pa_first + pend_i) * 9, ray, 0.001, tbest, t)) { tbest = t; kbest = lkind; ibest = pa_first + pend_i; }
+                    if (triangle_t(sc.tri_v + (size_t)prim * 9, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
             } else if (do_sph) {
                 if (is_leaf && lkind == ZR_PRIM_SPHERE) {
                     double t;
                     if (COUNT) c_sph++;
-                    if (sphere_t(sc.spheres + (size_t)(pa_first + pend_i) * 4, ray, 0.001, tbest, t)) { tbest = t; kbest = lkind; ibest = pa_first + pend_i; }
+                    if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
             } else if (GENERIC && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
                 if (COUNT) {
                     uint32_t kk = lkind;
-                    if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[pa_first + pend_i].type;
+                    if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[prim].type;
                     if (kk == ZR_PRIM_SPHERE) c_sph++; else if (kk == ZR_PRIM_TRIANGLE) c_tri++; else if (kk == ZR_PRIM_CUBE) c_cube++; else c_med++;
                 }
-                if (object_t(sc, lkind, pa_first + pend_i, ray, 0.001, tbest, g, t)) { tbest = t; kbest = lkind; ibest = pa_first + pend_i; }
+                if (object_t(sc, lkind, prim, ray, 0.001, tbest, g, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                 tested = true;
             }
             if (tested) {
                 pend_i++;
-                if (pend_i >= (pa_meta & 0xFFFFu)) {
-                    pa_first = pb_first; pa_meta = pb_meta; pb_meta = 0; pend_i = 0;
-                    if (pa_meta == 0) {
-                        if (cur == NONE) pop_next();
-                        if (cur != NONE) st = X_NODE; else finish();
-                    }
-                }
+                if (pend_i > ((cur >> 24) & 0xFu)) { ZR_POP_NEXT() }
             }
         }
     }
