@@ -55,7 +55,8 @@ __device__ __forceinline__ void set_face(Rec& rec, V3 rd, V3 outward) {  // hitt
 struct Rng {
     uint64_t key, k;
     uint32_t bounce;
-    __device__ __forceinline__ double next() { return zr_bits_to_unit(zr_stream_bits(key, k++)); }
+    // zr_stream_bits(key, k) = mix64(key + GOLDEN * (k + 1)); the product is one 64-bit multiply the counter can skip
+    __device__ __forceinline__ double next() { k++; return zr_bits_to_unit(zr_mix64(key + ZR_GOLDEN * k)); }
     __device__ __forceinline__ double range(double a, double b) { return a + (b - a) * next(); }
 };
 

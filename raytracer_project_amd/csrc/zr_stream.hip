@@ -317,8 +317,32 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 template <bool COUNT>
 __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
                                                     unsigned long long* __restrict__ gctr) {
-    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot < ST_SHARDS) B.ctl[16 + 32 * slot + 8] = 0;  // EXTEND of the next round starts from chunk 0 of every shard
+    const uint32_t slot0 = blockIdx.x * 256 + threadIdx.x;
+    if (slot0 < ST_SHARDS) B.ctl[16 + 32 * slot0 + 8] = 0;  // EXTEND of the next round starts from chunk 0 of every shard
+    // In-block partition: the 256 slots of this block are re-dealt to its threads so that slots whose ray HIT come
+    // first and misses / inactive slots last.  The hit path (hit record + scatter with its rejection sampler) and the
+    // miss path (background) are both long; unsorted, almost every wave runs both under half-empty exec masks.
+    __shared__ unsigned char perm[256];
+    __shared__ unsigned int wave_hits[4];
+    uint32_t slot;
+    {
+        bool is_hit = false;
+        if (slot0 < B.P) {
+            const uint2 m0 = B.ld2(SF_MA, slot0);
+            if (m0.y & F_ACTIVE) is_hit = B.ld2(SF_HIT_KI, slot0).x != 0xFFFFFFFFu;
+        }
+        const int w = threadIdx.x >> 6, wl = threadIdx.x & 63;
+        const unsigned long long hm = __ballot(is_hit);
+        if (wl == 0) wave_hits[w] = (unsigned int)__popcll(hm);
+        __syncthreads();
+        unsigned int hits_before = 0, hits_total = 0;
+        for (int k = 0; k < 4; k++) { if (k < w) hits_before += wave_hits[k]; hits_total += wave_hits[k]; }
+        const unsigned int rank_hit = hits_before + (unsigned int)__popcll(hm & ((1ull << wl) - 1ull));
+        const unsigned int rank_miss = (unsigned int)(w * 64 + wl) - rank_hit;   // non-hits before this thread
+        perm[is_hit ? rank_hit : hits_total + rank_miss] = (unsigned char)threadIdx.x;
+        __syncthreads();
+        slot = blockIdx.x * 256 + perm[threadIdx.x];
+    }
     bool active_after = false, want_unit = false;
     uint32_t c_samp = 0; unsigned long long c_draws = 0;
     if (slot < B.P) {
