@@ -79,6 +79,7 @@ struct DevBuf {
 struct zr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // second stream of the streaming pipeline (half pool B)
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
@@ -94,6 +95,8 @@ struct zr_ctx {
     DevBuf<unsigned char> d_st_overflow;
     int st_blocks = 0;
     uint32_t st_slots = 0;
+    bool st_overlap = true;               // two half pools half a round apart on two streams
+    hipEvent_t st_event = nullptr;
     unsigned int* h_active = nullptr;     // pinned
     std::vector<int32_t> pix_key;         // plan the cached pixel list was built for
     uint64_t last_rounds = 0;
@@ -421,6 +424,9 @@ zr_ctx* zr_create(int device_ordinal) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) {
+        fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
+    }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
     c->variant = (int)env_double("ZR_KERNEL", 2);
     c->log_kind = (int)env_double("ZR_TIMELOG_KIND", 1);
@@ -430,8 +436,10 @@ zr_ctx* zr_create(int device_ordinal) {
         if (over > 0) c->st_blocks = over;
         c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
-        if (c->d_ctl.alloc(zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
-            hipHostMalloc((void**)&c->h_active, zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
+        c->st_overlap = env_double("ZR_STREAM_OVERLAP", 0) != 0;  // measured: +1.7 % throughput, but both kernels then share HBM and the EXTEND launches stretch by 50 %
+        if (c->d_ctl.alloc(3 * zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(2 * zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
+            hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void**)&c->h_active, 2 * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
     if (c->variant == 1) {
         c->wf_blocks = zr::wavefront_max_blocks();
@@ -452,7 +460,9 @@ void zr_destroy(zr_ctx* c) {
     c->d_pool.release(); c->d_pixels.release(); c->d_partial.release(); c->d_ctl.release(); c->d_st_overflow.release();
     c->d_task.release(); c->d_overflow.release();
     if (c->h_active) (void)hipHostFree(c->h_active);
+    if (c->st_event) (void)hipEventDestroy(c->st_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -775,20 +785,18 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     if ((uint64_t)n_pix * lanes > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x lanes must fit 32 bits)");
     if ((uint64_t)n_pix * lanes < P) P = n_pix * lanes;
     int rc;
-    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots)))) return rc;
+    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536))) return rc;
     const size_t partial_n = (size_t)n_pix * lanes * 3;
     if (c->d_partial.n < partial_n) { if ((rc = c->d_partial.alloc(partial_n))) return rc; }
     HIP_OK(hipMemsetAsync(c->d_partial.p, 0, partial_n * sizeof(double), stream));
     HostTimer timer(c);
     int rounds = 0;
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, lanes, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
-                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, &timer, c->h_active, keep_going, &rounds, s->generic_leaves);
+                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, c->stream2, c->st_event, &timer, c->h_active,
+                                     keep_going, &rounds, s->generic_leaves, c->st_overlap);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
-    unsigned int ctl[4] = {0, 0, 0, 0};
-    HIP_OK(hipMemcpyAsync(ctl, c->d_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
-    if (ctl[2] != 0) return fail(ZR_E_DEVICE, "EXTEND kernel hit its iteration cap in %u wave(s)", ctl[2]);
     if (rounds < 0) return fail(ZR_E_CANCELLED, "render cancelled after %d rounds", -rounds);
     return ZR_OK;
 }

@@ -57,7 +57,10 @@ struct StreamBuf {
     unsigned int* ctl;        // [2] iteration-cap hits; per shard s: [16 + 32 s] unit counter, [16 + 32 s + 8] EXTEND chunk head,
                               // [16 + 32 s + 16] active slots after the last SHADE (ST_SHARDS words on separate cache lines:
                               // a single contended word sustains only ~90 atomics/us)
+    unsigned int* uctl;       // work-unit counters [32 s], shared by the two half pools
     uint32_t P, lanes, n_units, n_pix;
+    uint32_t unit0;           // slot k of this pool starts on unit unit0 + k
+    uint32_t unit_base;       // first dynamically assigned unit (= slots of both pools)
     __device__ __forceinline__ double* cell(int f, uint32_t slot) const { return pool + ((size_t)(slot >> 6) * SF_N + f) * 64 + (slot & 63u); }
     __device__ __forceinline__ double ld(int f, uint32_t slot) const { return *cell(f, slot); }
     __device__ __forceinline__ void st(int f, uint32_t slot, double v) const { *cell(f, slot) = v; }
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
     if (slot >= B.P) return;
     B.st3(SF_SUM, slot, mk(0, 0, 0));
     uint32_t c_samp = 0;
-    if (slot < B.n_units) begin_sample(B, cam, seed, slot, slot, slot % B.lanes, c_samp);
+    if (B.unit0 + slot < B.n_units) begin_sample(B, cam, seed, slot, B.unit0 + slot, (B.unit0 + slot) % B.lanes, c_samp);
     else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
@@ -444,11 +447,11 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             const uint32_t shard = blockIdx.x % ST_SHARDS;
             const int wl = threadIdx.x & 63;
             uint32_t k0 = 0;
-            if (wl == (int)__builtin_ctzll(wm)) k0 = atomicAdd(&B.ctl[16 + 32 * shard], (unsigned int)__popcll(wm));
+            if (wl == (int)__builtin_ctzll(wm)) k0 = atomicAdd(&B.uctl[32 * shard], (unsigned int)__popcll(wm));
             k0 = __shfl(k0, (int)__builtin_ctzll(wm), 64);
             if (want_unit) {
                 const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
-                const unsigned long long u = (unsigned long long)B.P + k * ST_SHARDS + shard;
+                const unsigned long long u = (unsigned long long)B.unit_base + k * ST_SHARDS + shard;
                 if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, (uint32_t)(u % B.lanes), c_samp); active_after = true; }
                 else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
             }
@@ -497,60 +500,92 @@ int stream_extend_blocks() {
 size_t stream_pool_bytes(uint32_t P) { return ((size_t)(P + 63) / 64) * SF_N * 64 * sizeof(double); }
 
 static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t n_units, uint32_t n_pix, const uint32_t* pixels, double* partial,
-                          unsigned int* ctl) {
+                          unsigned int* ctl, unsigned int* uctl, uint32_t unit0, uint32_t unit_base) {
     StreamBuf B;
-    B.pool = (double*)pool; B.pixels = pixels; B.partial = partial; B.ctl = ctl;
-    B.P = P; B.lanes = lanes; B.n_units = n_units; B.n_pix = n_pix;
+    B.pool = (double*)pool; B.pixels = pixels; B.partial = partial; B.ctl = ctl; B.uctl = uctl;
+    B.P = P; B.lanes = lanes; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base;
     return B;
 }
 
+template <bool COUNT>
+static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, int blocks, unsigned long long* gctr, bool generic, hipStream_t st) {
+    if (generic) hipLaunchKernelGGL((stream_extend<COUNT, true>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
+    else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
+}
+
+// The slot pool is split into two halves that run half a round apart on two HIP streams: while one half is in
+// EXTEND (dependent BVH fetches, ALU) the other is in SHADE (HBM-bandwidth bound state streaming), so the two stages
+// overlap on the chip instead of alternating.  `stream` is the caller's stream (half A), `stream2` an internal one.
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t lanes,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_partial, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
-                         double* out, unsigned long long* gctr, bool count, hipStream_t stream, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic) {
+                         double* out, unsigned long long* gctr, bool count, hipStream_t stream, hipStream_t stream2, hipEvent_t ev, StreamTimer* timer,
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, bool overlap) {
     const uint32_t n_units = n_pix * lanes;
-    StreamBuf B = make_buf(pool, P, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl);
+    const size_t W = stream_ctl_words();
+    // two halves (B empty when the pool is small or overlap is off)
+    uint32_t PA = P, PB = 0;
+    if (overlap && P >= 2u * 64u * 1024u) { PA = (P / 2 + 63) / 64 * 64; PB = P - PA; }
+    StreamBuf A = make_buf(pool, PA, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl, d_ctl + 2 * W, 0, P);
+    StreamBuf Bb = make_buf((unsigned char*)pool + stream_pool_bytes(PA), PB, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl + W, d_ctl + 2 * W, PA, P);
+    void* ovA = d_overflow;
+    void* ovB = (unsigned char*)d_overflow + stream_overflow_bytes(extend_blocks);
     hipError_t e;
-    if ((e = hipMemsetAsync(d_ctl, 0, stream_ctl_words() * sizeof(unsigned int), stream)) != hipSuccess) return e;
-    const unsigned pblocks = (P + 255) / 256;
-    if (timer) timer->begin(stream, 0);
-    if (count) hipLaunchKernelGGL(stream_init<true>, dim3(pblocks), dim3(256), 0, stream, B, cam, seed, gctr);
-    else hipLaunchKernelGGL(stream_init<false>, dim3(pblocks), dim3(256), 0, stream, B, cam, seed, gctr);
-    if (timer) timer->end(stream, 0);
-    h_active[0] = 1;
-    int rounds = 0;
+    if ((e = hipMemsetAsync(d_ctl, 0, 3 * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    auto init = [&](const StreamBuf& Q, hipStream_t st) {
+        if (timer) timer->begin(st, 0);
+        if (count) hipLaunchKernelGGL(stream_init<true>, dim3((Q.P + 255) / 256), dim3(256), 0, st, Q, cam, seed, gctr);
+        else hipLaunchKernelGGL(stream_init<false>, dim3((Q.P + 255) / 256), dim3(256), 0, st, Q, cam, seed, gctr);
+        if (timer) timer->end(st, 0);
+    };
+    auto extend = [&](const StreamBuf& Q, void* ov, hipStream_t st) {
+        const int eb = (int)((Q.P + 63) / 64 < (uint32_t)extend_blocks ? (Q.P + 63) / 64 : (uint32_t)extend_blocks);
+        if (timer) timer->begin(st, 1);
+        if (count) launch_extend<true>(sc, Q, ov, eb, gctr, generic, st); else launch_extend<false>(sc, Q, ov, eb, gctr, generic, st);
+        if (timer) timer->end(st, 1);
+    };
+    auto shade = [&](const StreamBuf& Q, hipStream_t st) {
+        if (timer) timer->begin(st, 2);
+        if (count) hipLaunchKernelGGL(stream_shade<true>, dim3((Q.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, Q, gctr);
+        else hipLaunchKernelGGL(stream_shade<false>, dim3((Q.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, Q, gctr);
+        if (timer) timer->end(st, 2);
+    };
+    init(A, stream);
+    if (PB) {
+        // half B starts after the buffers are initialised and half a round late: it waits for A's first EXTEND
+        extend(A, ovA, stream);
+        if ((e = hipEventRecord(ev, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream2, ev, 0)) != hipSuccess) return e;
+        init(Bb, stream2);
+        shade(A, stream);
+    }
+    int rounds = PB ? 1 : 0;
     int check_every = 8;
-    const int eb = (int)((P + 63) / 64 < (uint32_t)extend_blocks ? (P + 63) / 64 : (uint32_t)extend_blocks);
     bool cancelled = false;
     for (;;) {
         for (int k = 0; k < check_every; k++) {
-            if (timer) timer->begin(stream, 1);
-            if (generic) {
-                if (count) hipLaunchKernelGGL((stream_extend<true, true>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
-                else hipLaunchKernelGGL((stream_extend<false, true>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
-            } else {
-                if (count) hipLaunchKernelGGL((stream_extend<true, false>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
-                else hipLaunchKernelGGL((stream_extend<false, false>), dim3(eb), dim3(64), 0, stream, sc, B, (SEntry*)d_overflow, gctr);
-            }
-            if (timer) timer->end(stream, 1);
-            if (timer) timer->begin(stream, 2);
-            if (count) hipLaunchKernelGGL(stream_shade<true>, dim3(pblocks), dim3(256), 0, stream, sc, cam, env, seed, B, gctr);
-            else hipLaunchKernelGGL(stream_shade<false>, dim3(pblocks), dim3(256), 0, stream, sc, cam, env, seed, B, gctr);
-            if (timer) timer->end(stream, 2);
+            if (PB) { extend(Bb, ovB, stream2); shade(Bb, stream2); }
+            extend(A, ovA, stream); shade(A, stream);
             rounds++;
         }
-        if ((e = hipMemcpyAsync(h_active, d_ctl, stream_ctl_words() * sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(h_active, d_ctl, 2 * W * sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+        if (PB) {
+            // the copy on `stream` must see half B's counters: join stream2 into stream first
+            if ((e = hipStreamSynchronize(stream2)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(h_active + W, d_ctl + W, W * sizeof(unsigned int), hipMemcpyDeviceToHost, stream2)) != hipSuccess) break;
+            if ((e = hipStreamSynchronize(stream2)) != hipSuccess) break;
+        }
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
         unsigned long long active = 0;
-        for (int sh = 0; sh < ST_SHARDS; sh++) active += h_active[16 + 32 * sh + 16];
+        for (int sh = 0; sh < ST_SHARDS; sh++) active += (unsigned long long)h_active[16 + 32 * sh + 16] + (PB ? h_active[W + 16 + 32 * sh + 16] : 0u);
         if (active == 0) break;
         check_every = active > P / 2 ? 8 : (active > P / 16 ? 4 : 2);
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }
     if (e != hipSuccess) return e;
+    if (h_active[2] != 0 || (PB && h_active[W + 2] != 0)) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
     if (timer) timer->begin(stream, 3);
-    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 255) / 256), dim3(256), 0, stream, B, cam, out);
+    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 255) / 256), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
     if (rounds_out) *rounds_out = cancelled ? -rounds : rounds;
     return hipGetLastError();
