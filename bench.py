@@ -80,6 +80,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if os.environ.get("ZR_BENCH_ONE_DEVICE"):   # rehearsal of the N > 1 path on a one-GPU box (gloo): every rank on device 0
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -119,10 +121,7 @@ def main():
     # the dominant kernel of the streaming pipeline is EXTEND (BVH walk): it owns the box / primitive bytes; the 76 B of
     # shading data per hit belong to the SHADE kernel and are left out of the EXTEND roofline
     bytes_local = ctr.algorithmic_bytes() - (76 * ctr.hits if int(os.environ.get("ZR_KERNEL", "2")) == 2 else 0)
-    tot = torch.tensor([seg_local, bytes_local, ctr.primary_samples], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tot)
-    segments, alg_bytes, primary = (float(x) for x in tot.tolist())
+    segments, alg_bytes, primary = multi.all_reduce_values([seg_local, bytes_local, ctr.primary_samples], world, dev)
     checksum = float(acc.sum().item()) if rank == 0 else 0.0
 
     for _ in range(args.warmup):
@@ -134,10 +133,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = multi.all_reduce_values([dt], world, dev, op="max")[0]
     launches = ctx.kernel_times_ms(1 << 20)  # dominant kernel's launches (HIP events on the launch stream), timed steps only
     variant = int(os.environ.get("ZR_KERNEL", "2"))
     kernel_name = {0: "render_pixels", 1: "render_wavefront", 2: "stream_extend"}.get(variant, "?")

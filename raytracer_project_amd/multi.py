@@ -34,7 +34,7 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("ZR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -42,12 +42,31 @@ def init_distributed(backend=None):
 
 
 def reduce_frame(acc, world, dst=0):
-    """The one collective of a frame: sum the per-rank accumulators (disjoint tiles) onto rank `dst`."""
+    """The one collective of a frame: sum the per-rank accumulators (disjoint tiles) onto rank `dst`.
+    With the gloo backend (rehearsals on a box without one GPU per rank) device tensors are staged through the host."""
     if world <= 1:
         return acc
     import torch.distributed as dist
+    if dist.get_backend() == "gloo" and acc.is_cuda:
+        host = acc.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == dst:
+            acc.copy_(host)
+        return acc
     dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
     return acc
+
+
+def all_reduce_values(values, world, device, op="sum"):
+    """all-reduce a short list of Python floats (bookkeeping: segment counts, elapsed time)."""
+    import torch
+    if world <= 1:
+        return list(values)
+    import torch.distributed as dist
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t.tolist()
 
 
 def render_frame(render_tiles, acc, rank, world):
