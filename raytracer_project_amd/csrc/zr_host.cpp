@@ -780,18 +780,26 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     c->render_id++; c->last_stream = stream; c->last_counted = count != 0; c->last_rounds = 0;
     HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
     if (n_pix == 0) return ZR_OK;
-    const uint32_t lanes = (uint32_t)plan.lanes;
-    uint32_t P = c->st_slots / lanes * lanes;
-    if ((uint64_t)n_pix * lanes > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x lanes must fit 32 bits)");
-    if ((uint64_t)n_pix * lanes < P) P = n_pix * lanes;
+    const uint32_t spp = (uint32_t)dc.spp;
+    const uint64_t units = (uint64_t)n_pix * spp;   // one work unit per primary sample
+    if (units > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x spp must fit 32 bits); shard it or set ZR_KERNEL=1");
+    // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
+    // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
+    uint32_t P = c->st_slots / 64 * 64;
+    {
+        uint64_t want = std::max<uint64_t>(units / (uint64_t)std::max(1.0, env_double("ZR_STREAM_UNITS_PER_SLOT", 8)), 1u << 20);
+        want = want / 64 * 64;
+        if (want < P) P = (uint32_t)want;
+        if (units < P) P = (uint32_t)((units + 63) / 64 * 64);
+    }
     int rc;
     if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536))) return rc;
-    const size_t partial_n = (size_t)n_pix * lanes * 3;
-    if (c->d_partial.n < partial_n) { if ((rc = c->d_partial.alloc(partial_n))) return rc; }
-    HIP_OK(hipMemsetAsync(c->d_partial.p, 0, partial_n * sizeof(double), stream));
+    const size_t samples_n = (size_t)units * 3;
+    if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
+    if (keep_going) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame reduces what exists
     HostTimer timer(c);
     int rounds = 0;
-    hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, lanes, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
+    hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, c->stream2, c->st_event, &timer, c->h_active,
                                      keep_going, &rounds, s->generic_leaves, c->st_overlap);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));

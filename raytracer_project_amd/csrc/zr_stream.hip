@@ -11,13 +11,15 @@
 //           SHADE   one thread per slot: hit record, emission, scatter, Russian roulette, background; a finished
 //                   path adds its radiance to the SLOT's running sum and the slot starts its next sample in place
 //                   (regeneration), so every slot carries exactly one segment per round until the frame drains
-//   end:    REDUCE  slot sums were written to partial[pixel][lane] when a slot left a pixel; one fixed-order sum
-//                   per pixel gives the mean — no atomics on radiance anywhere, the image is bit-reproducible
+//   end:    REDUCE  every finished sample wrote its radiance to samples[pixel][s]; one fixed-order sum per pixel
+//                   gives the mean — no atomics on radiance anywhere, the image is bit-reproducible
 //
-// Work units: unit u = (pixel u / LANES of the frame's pixel list, lane j = u % LANES) = samples j, j + LANES, ... of
-// that pixel.  Slot k starts on unit k; a slot that finishes its unit writes its sum to partial[pixel][j] and takes
-// the next unit from one of ST_SHARDS interleaved counters (one atomic per wave per round, spread over ST_SHARDS
-// cache lines).  Which slot computes a unit does not affect the unit's value, so the image is deterministic.
+// Work units: unit u = one primary sample = (pixel u / spp of the frame's pixel list, sample u % spp).  Slot k starts on
+// unit k (64 consecutive slots = one pixel: coherent primary rays); a slot whose path ends writes the sample's
+// radiance to samples[u] and takes the next unit from one of ST_SHARDS interleaved counters (one atomic per wave per
+// round, spread over ST_SHARDS cache lines).  Every sample is written exactly once, by whichever slot computed it, and
+// REDUCE sums a pixel's samples in an order that depends only on spp — so the image is bit-reproducible and does not
+// depend on the pool size, on scheduling, or on how the frame is sharded over GPUs.
 #include "zr_device.h"
 #include "zr_launch.h"
 
@@ -39,7 +41,7 @@ namespace zr {
 #define ST_LDS_STACK 12
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
-enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17 };  // meta.y: bounce | b_inner << 8 | flags
+enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18 };  // meta.y: bounce | b_inner << 8 | flags (F_L0: SF_SUM holds the primary hit's emission)
 
 struct SEntry { uint32_t node; float tn; };
 
@@ -48,17 +50,17 @@ struct SEntry { uint32_t node; float tn; };
 // 512-B row, and all of a slot's state shares a page (a plain [field][P] layout put each of the 23 fields 128 MB
 // apart and ran the SHADE stage at 1.7 TB/s).
 enum { SF_RAY = 0, SF_HIT_T = 6, SF_HIT_KI = 7, SF_BETA = 8, SF_L = 11, SF_ATT0 = 14, SF_SUM = 17, SF_KEY = 20,
-       SF_MA = 21 /* RNG draw index, bounce | b_inner << 8 | flags */, SF_MB = 22 /* work unit, sample */, SF_N = 24 };
+       SF_MA = 21 /* RNG draw index, bounce | b_inner << 8 | flags */, SF_MB = 22 /* work unit */, SF_N = 24 };
 
 struct StreamBuf {
     double* pool;             // [P / 64][SF_N][64] 8-byte cells
     const uint32_t* pixels;   // [n_pix] px | py << 16
-    double* partial;          // [n_pix][lanes][3]
+    double* samples;          // [n_pix][spp][3] radiance of every primary sample
     unsigned int* ctl;        // [2] iteration-cap hits; per shard s: [16 + 32 s] unit counter, [16 + 32 s + 8] EXTEND chunk head,
                               // [16 + 32 s + 16] active slots after the last SHADE (ST_SHARDS words on separate cache lines:
                               // a single contended word sustains only ~90 atomics/us)
     unsigned int* uctl;       // work-unit counters [32 s], shared by the two half pools
-    uint32_t P, lanes, n_units, n_pix;
+    uint32_t P, spp, n_units, n_pix;
     uint32_t unit0;           // slot k of this pool starts on unit unit0 + k
     uint32_t unit_base;       // first dynamically assigned unit (= slots of both pools)
     __device__ __forceinline__ double* cell(int f, uint32_t slot) const { return pool + ((size_t)(slot >> 6) * SF_N + f) * 64 + (slot & 63u); }
@@ -72,16 +74,16 @@ struct StreamBuf {
 
 
 // ---- begin a sample in a slot: camera ray + fresh path state --------------------------------------------
-__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t sample,
-                                    uint32_t& c_samp) {
-    const uint32_t pk = B.pixels[unit / B.lanes];
+__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t& c_samp) {
+    const uint32_t pix_i = unit / B.spp, sample = unit - pix_i * B.spp;
+    const uint32_t pk = B.pixels[pix_i];
     const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
     Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)sample); g.k = 0; g.bounce = 0;
     Ray r = camera_ray(cam, px, py, g);
     B.st3(SF_RAY, slot, r.o); B.st3(SF_RAY + 3, slot, r.d);
     B.st(SF_KEY, slot, __longlong_as_double((long long)g.key));
     uint2 ma; ma.x = (uint32_t)g.k; ma.y = F_FIRST | F_ACTIVE;
-    uint2 mb; mb.x = unit; mb.y = sample;
+    uint2 mb; mb.x = unit; mb.y = 0;
     B.st2(SF_MA, slot, ma); B.st2(SF_MB, slot, mb);
     c_samp++;
 }
@@ -90,9 +92,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uint64_t seed, unsigned long long* __restrict__ gctr) {
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= B.P) return;
-    B.st3(SF_SUM, slot, mk(0, 0, 0));
     uint32_t c_samp = 0;
-    if (B.unit0 + slot < B.n_units) begin_sample(B, cam, seed, slot, B.unit0 + slot, (B.unit0 + slot) % B.lanes, c_samp);
+    if (B.unit0 + slot < B.n_units) begin_sample(B, cam, seed, slot, B.unit0 + slot, c_samp);
     else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
@@ -352,7 +353,6 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
         uint2 m = B.ld2(SF_MA, slot);
         if (m.y & F_ACTIVE) {
             const uint32_t NONE = 0xFFFFFFFFu;
-            const uint2 mb = B.ld2(SF_MB, slot);
             Ray ray; ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
             const uint2 ki = B.ld2(SF_HIT_KI, slot);
             Rng g; g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, slot)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
@@ -412,31 +412,25 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     }
                 }
                 if (!ended) {
-                    // the path continues: publish the scattered ray
+                    // the path continues: publish the scattered ray (a primary hit's emission waits in SF_SUM)
                     B.st3(SF_RAY, slot, nr.o); B.st3(SF_RAY + 3, slot, nr.d);
-                    m.x = (uint32_t)g.k; m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE;
+                    if (has_add) B.st3(SF_SUM, slot, add_now);
+                    m.x = (uint32_t)g.k;
+                    m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE | (first ? (has_add ? F_L0 : 0u) : (m.y & F_L0));
                     B.st2(SF_MA, slot, m);
                     active_after = true;
                 }
             }
-            if (has_add && !ended) B.st3(SF_SUM, slot, B.ld3(SF_SUM, slot) + add_now);
             if (ended) {
-                V3 sum = B.ld3(SF_SUM, slot);
-                if (has_add) sum = sum + add_now;
-                sum = sum + contrib;
+                // radiance of this sample = L0 + att0 * L (camera.hpp:1000), written exactly once
+                V3 rad = contrib;
+                if (has_add) rad = add_now + rad;
+                else if (!first && (m.y & F_L0)) rad = B.ld3(SF_SUM, slot) + rad;
+                const uint32_t unit = B.ld2(SF_MB, slot).x;
+                double* pp = B.samples + (size_t)unit * 3;
+                pp[0] = rad.x; pp[1] = rad.y; pp[2] = rad.z;
                 if (COUNT) c_draws += g.k;
-                // next sample of this unit, or a new unit
-                const uint32_t sample = mb.y + B.lanes;
-                if (sample < (uint32_t)cam.spp) {
-                    B.st3(SF_SUM, slot, sum);
-                    begin_sample(B, cam, seed, slot, mb.x, sample, c_samp);
-                    active_after = true;
-                } else {
-                    double* pp = B.partial + (size_t)mb.x * 3;  // = [pixel][lane][3]
-                    pp[0] = sum.x; pp[1] = sum.y; pp[2] = sum.z;
-                    B.st3(SF_SUM, slot, mk(0, 0, 0));
-                    want_unit = true;
-                }
+                want_unit = true;
             }
         }
     }
@@ -452,7 +446,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             if (want_unit) {
                 const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
                 const unsigned long long u = (unsigned long long)B.unit_base + k * ST_SHARDS + shard;
-                if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, (uint32_t)(u % B.lanes), c_samp); active_after = true; }
+                if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, c_samp); active_after = true; }
                 else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
             }
         }
@@ -467,17 +461,27 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     }
 }
 
+// one wave per pixel: lane l sums samples l, l + 64, ... in order, then a fixed xor butterfly — the order depends on
+// spp only, never on which slot produced a sample
 __global__ __launch_bounds__(256) void stream_reduce(StreamBuf B, DCamera cam, double* __restrict__ out) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= B.n_pix) return;
-    const uint32_t pk = B.pixels[i];
-    const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
-    const double* pp = B.partial + (size_t)i * B.lanes * 3;
+    const double* pp = B.samples + (size_t)i * B.spp * 3;
     double sx = 0, sy = 0, sz = 0;
-    for (uint32_t j = 0; j < B.lanes; j++) { sx += pp[j * 3]; sy += pp[j * 3 + 1]; sz += pp[j * 3 + 2]; }
-    const double scale = 1.0 / cam.spp;  // camera.hpp:437,531
-    double* o = out + ((size_t)py * cam.W + px) * 3;
-    o[0] = sx * scale; o[1] = sy * scale; o[2] = sz * scale;
+    for (uint32_t sidx = (uint32_t)lane; sidx < B.spp; sidx += 64) { sx += pp[sidx * 3]; sy += pp[sidx * 3 + 1]; sz += pp[sidx * 3 + 2]; }
+    for (int m = 32; m >= 1; m >>= 1) {
+        sx += __hiloint2double(__shfl_xor(__double2hiint(sx), m, 64), __shfl_xor(__double2loint(sx), m, 64));
+        sy += __hiloint2double(__shfl_xor(__double2hiint(sy), m, 64), __shfl_xor(__double2loint(sy), m, 64));
+        sz += __hiloint2double(__shfl_xor(__double2hiint(sz), m, 64), __shfl_xor(__double2loint(sz), m, 64));
+    }
+    if (lane == 0) {
+        const uint32_t pk = B.pixels[i];
+        const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
+        const double scale = 1.0 / cam.spp;  // camera.hpp:437,531
+        double* o = out + ((size_t)py * cam.W + px) * 3;
+        o[0] = sx * scale; o[1] = sy * scale; o[2] = sz * scale;
+    }
 }
 
 // ---- host-side launch helpers -----------------------------------------------------------------------------------
@@ -499,11 +503,11 @@ int stream_extend_blocks() {
 // layout of the slot pool inside one allocation; returns bytes needed
 size_t stream_pool_bytes(uint32_t P) { return ((size_t)(P + 63) / 64) * SF_N * 64 * sizeof(double); }
 
-static StreamBuf make_buf(void* pool, uint32_t P, uint32_t lanes, uint32_t n_units, uint32_t n_pix, const uint32_t* pixels, double* partial,
+static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units, uint32_t n_pix, const uint32_t* pixels, double* samples,
                           unsigned int* ctl, unsigned int* uctl, uint32_t unit0, uint32_t unit_base) {
     StreamBuf B;
-    B.pool = (double*)pool; B.pixels = pixels; B.partial = partial; B.ctl = ctl; B.uctl = uctl;
-    B.P = P; B.lanes = lanes; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base;
+    B.pool = (double*)pool; B.pixels = pixels; B.samples = samples; B.ctl = ctl; B.uctl = uctl;
+    B.P = P; B.spp = spp; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base;
     return B;
 }
 
@@ -516,17 +520,17 @@ static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, 
 // The slot pool is split into two halves that run half a round apart on two HIP streams: while one half is in
 // EXTEND (dependent BVH fetches, ALU) the other is in SHADE (HBM-bandwidth bound state streaming), so the two stages
 // overlap on the chip instead of alternating.  `stream` is the caller's stream (half A), `stream2` an internal one.
-hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t lanes,
-                         uint32_t n_pix, const uint32_t* d_pixels, double* d_partial, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
+hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
+                         uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t stream, hipStream_t stream2, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, bool overlap) {
-    const uint32_t n_units = n_pix * lanes;
+    const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     // two halves (B empty when the pool is small or overlap is off)
     uint32_t PA = P, PB = 0;
     if (overlap && P >= 2u * 64u * 1024u) { PA = (P / 2 + 63) / 64 * 64; PB = P - PA; }
-    StreamBuf A = make_buf(pool, PA, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl, d_ctl + 2 * W, 0, P);
-    StreamBuf Bb = make_buf((unsigned char*)pool + stream_pool_bytes(PA), PB, lanes, n_units, n_pix, d_pixels, d_partial, d_ctl + W, d_ctl + 2 * W, PA, P);
+    StreamBuf A = make_buf(pool, PA, spp, n_units, n_pix, d_pixels, d_samples, d_ctl, d_ctl + 2 * W, 0, P);
+    StreamBuf Bb = make_buf((unsigned char*)pool + stream_pool_bytes(PA), PB, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + W, d_ctl + 2 * W, PA, P);
     void* ovA = d_overflow;
     void* ovB = (unsigned char*)d_overflow + stream_overflow_bytes(extend_blocks);
     hipError_t e;
@@ -585,7 +589,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     if (e != hipSuccess) return e;
     if (h_active[2] != 0 || (PB && h_active[W + 2] != 0)) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
     if (timer) timer->begin(stream, 3);
-    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 255) / 256), dim3(256), 0, stream, A, cam, out);
+    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
     if (rounds_out) *rounds_out = cancelled ? -rounds : rounds;
     return hipGetLastError();
