@@ -101,6 +101,8 @@ def main():
     H, W = cam.image_height, cam.image_width
     acc = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
     region = multi.tile_region(capi, rank, world)
+    if os.environ.get("ZR_BENCH_SHARD_OF"):  # development aid: time one rank's share of an N-way sharded frame on one GPU
+        region = multi.tile_region(capi, 0, int(os.environ["ZR_BENCH_SHARD_OF"]))
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(count=False):

@@ -95,7 +95,7 @@ struct zr_ctx {
     DevBuf<unsigned char> d_st_overflow;
     int st_blocks = 0;
     uint32_t st_slots = 0;
-    bool st_overlap = true;               // two half pools half a round apart on two streams
+    int st_overlap = -1;                  // two half pools half a round apart on two streams: 0 off, 1 on, -1 auto
     hipEvent_t st_event = nullptr;
     unsigned int* h_active = nullptr;     // pinned
     std::vector<int32_t> pix_key;         // plan the cached pixel list was built for
@@ -436,7 +436,9 @@ zr_ctx* zr_create(int device_ordinal) {
         if (over > 0) c->st_blocks = over;
         c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
-        c->st_overlap = env_double("ZR_STREAM_OVERLAP", 0) != 0;  // measured: +1.7 % throughput, but both kernels then share HBM and the EXTEND launches stretch by 50 %
+        // auto: on for sharded frames (a rank's 1/8 of cfg3: 71.8 -> 67.1 ms, the halves fill each other's ramp and
+        // tail), off for whole frames (+1 % only: the pipeline is HBM-bound and the co-running launches just stretch)
+        c->st_overlap = (int)env_double("ZR_STREAM_OVERLAP", -1);
         if (c->d_ctl.alloc(3 * zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(2 * zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
             hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&c->h_active, 2 * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
@@ -801,7 +803,8 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     int rounds = 0;
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, c->stream2, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->generic_leaves, c->st_overlap);
+                                     keep_going, &rounds, s->generic_leaves,
+                                     c->st_overlap < 0 ? (size_t)plan.tiles.size() < (size_t)plan.tiles_x * plan.tiles_y : c->st_overlap != 0);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));

@@ -1,4 +1,16 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "ZR_BVH_MAX_LEAF=4" "ZR_BVH_MAX_LEAF=2" "ZR_BVH_MAX_LEAF=8" "ZR_BVH_MAX_LEAF=8 ZR_BVH_COST_TRI=0.7" "ZR_BVH_COST_TRI=3" "ZR_BVH_COST_TRAVERSE=2" "ZR_BVH_COST_TRAVERSE=0.5" "ZR_BVH_MAX_LEAF=16 ZR_BVH_COST_TRI=0.5"; do
-echo "== $cfg"; env $cfg python scripts/stats.py cfg3:256 | grep Mseg | cut -c1-140
-done
+python3 - <<'PY'
+import sys,os,time; sys.path.insert(0,'.')
+import numpy as np
+from raytracer_project_amd import capi
+for kind in (1,2):
+    os.environ['ZR_TIMELOG_KIND']=str(kind)
+    ctx=capi.Context(0); ds=capi.DemoScene('cfg3'); sc=capi.Scene(ctx,ds.desc)
+    reg=capi.Region(0,0,0,0,32,8,0,0)
+    out=np.zeros((1080,1920,3))
+    sc.render(ds.camera,ds.env,ds.seed,reg,out=out); ctx.kernel_times_ms(100000)
+    sc.render(ds.camera,ds.env,ds.seed,reg,out=out)
+    c=ctx.counters(); t=ctx.kernel_times_ms(100000)
+    print('kind',kind,'rounds',c.rounds,'extend %.1f shade %.1f total %.1f'%(c.extend_ms,c.shade_ms,c.kernel_ms))
+    print('   per round:',' '.join('%.2f'%x for x in t))
+PY
