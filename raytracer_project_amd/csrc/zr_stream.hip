@@ -37,6 +37,9 @@ namespace zr {
 #ifndef ST_EXT_WAVES_LEAN
 #define ST_EXT_WAVES_LEAN 6  /* same for the triangles-and-spheres-only build of EXTEND */
 #endif
+#ifndef ST_FETCH_MIN
+#define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
+#endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #define ST_LDS_STACK 12
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
         if (n1 + n2 + n0 == 0) break;
 
-        if (n0 >= 16 || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
+        if (n0 >= ST_FETCH_MIN || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
             // ================= FETCH: idle lanes take the next ray indices =================
             // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays
             const unsigned long long idle = __ballot(st == X_IDLE);

@@ -1,16 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python3 - <<'PY'
-import sys,os,time; sys.path.insert(0,'.')
-import numpy as np
-from raytracer_project_amd import capi
-for kind in (1,2):
-    os.environ['ZR_TIMELOG_KIND']=str(kind)
-    ctx=capi.Context(0); ds=capi.DemoScene('cfg3'); sc=capi.Scene(ctx,ds.desc)
-    reg=capi.Region(0,0,0,0,32,8,0,0)
-    out=np.zeros((1080,1920,3))
-    sc.render(ds.camera,ds.env,ds.seed,reg,out=out); ctx.kernel_times_ms(100000)
-    sc.render(ds.camera,ds.env,ds.seed,reg,out=out)
-    c=ctx.counters(); t=ctx.kernel_times_ms(100000)
-    print('kind',kind,'rounds',c.rounds,'extend %.1f shade %.1f total %.1f'%(c.extend_ms,c.shade_ms,c.kernel_ms))
-    print('   per round:',' '.join('%.2f'%x for x in t))
-PY
+for cfg in "-DST_FETCH_MIN=16" "-DST_FETCH_MIN=8" "-DST_FETCH_MIN=32" "-DST_FETCH_MIN=48" "-DST_CHUNK=128" "-DST_CHUNK=512" "-DST_LDS_STACK=8" "-DST_LDS_STACK=16"; do
+  touch raytracer_project_amd/csrc/zr_stream.hip
+  make -s -C raytracer_project_amd/csrc "ZR_KFLAGS=$cfg" 2>&1 | grep -E "error" || true
+  echo "== $cfg"; python scripts/stats.py cfg3:256 | grep Mseg | cut -c1-110
+done
