@@ -642,7 +642,7 @@ inline aabb rotated_box(const aabb& in, int axis, double s, double c) {
     for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
         double x = i * in.x.max + (1 - i) * in.x.min, y = j * in.y.max + (1 - j) * in.y.min, z = k * in.z.max + (1 - k) * in.z.min;
         vec3 t(x, y, z);
-        if (axis == 1) { t[0] = c * x + s * z; t[2] = -s * x + c * z; }
+        if (axis == 1) { t[0] = c * x - s * z; t[2] = s * x + c * z; }  // the true map; rotate_y.hpp:26-27 uses the inverse
         else if (axis == 0) { t[1] = c * y - s * z; t[2] = s * y + c * z; }
         else { t[0] = c * x - s * y; t[1] = s * x + c * y; }
         for (int q = 0; q < 3; q++) { lo[q] = std::fmin(lo[q], t[q]); hi[q] = std::fmax(hi[q], t[q]); }
@@ -738,6 +738,100 @@ public:
     void flatten(zenith::scene_builder& b) const override { list.flatten(b); }
 private:
     hittable_list list;
+};
+
+
+// ---- model.hpp: OBJ mesh -> recentred, scaled triangles ------------------------------------------------
+// model(filename, mat, scale): /root/reference/model.hpp:12-103.  The reference parses with the vendored
+// tiny_obj_loader (float attributes, polygons triangulated); the drop-in has its own minimal Wavefront reader:
+// `v x y z [r g b]`, `vn`, `f` with v, v/vt, v//vn, v/vt/vn and negative (relative) indices.  Triangulation follows
+// tinyobj 2.0: quads are split along the SHORTER diagonal, compared in float ([0,1,2][0,2,3] if |v2-v0|^2 < |v3-v1|^2,
+// else [0,1,3][1,2,3]); polygons with more than four vertices are fanned (tinyobj ear-clips them: documented
+// deviation, the reference's assets contain triangles and quads only).
+// Semantics kept: the bounding box is taken over ALL `v` lines; x/z are centred on it and y-min moves to 0
+// (model.hpp:23-42); vertex = (v - offset) * scale in double (model.hpp:47-53); a face uses its vn normals when
+// its first corner has one, otherwise one flat normal unit(cross(v1-v0, v2-v0)) (model.hpp:70-85).
+class model : public hittable {
+public:
+    model(const std::string& filename, shared_ptr<material> mat, double scale = 1.0) : mat(mat) {
+        std::vector<float> V, N;
+        struct corner { int v, n; };
+        std::vector<std::vector<corner>> faces;
+        std::ifstream f(filename);
+        if (!f) { std::cerr << "Cannot load the model: " << filename << std::endl; return; }
+        std::string line;
+        while (std::getline(f, line)) {
+            const char* p = line.c_str();
+            while (*p == ' ' || *p == '\t') p++;
+            if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+                char* e; p += 2;
+                for (int k = 0; k < 3; k++) { V.push_back((float)std::strtod(p, &e)); p = e; }
+            } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+                char* e; p += 3;
+                for (int k = 0; k < 3; k++) { N.push_back((float)std::strtod(p, &e)); p = e; }
+            } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+                p += 2;
+                std::vector<corner> fc;
+                for (;;) {
+                    while (*p == ' ' || *p == '\t') p++;
+                    if (*p == 0 || *p == '\r' || *p == '\n' || *p == '#') break;
+                    char* e;
+                    long vi = std::strtol(p, &e, 10), ni = 0; bool has_n = false;
+                    if (e == p) break;
+                    p = e;
+                    if (*p == '/') {
+                        p++;
+                        if (*p != '/') { (void)std::strtol(p, &e, 10); p = e; }   // vt
+                        if (*p == '/') { p++; ni = std::strtol(p, &e, 10); has_n = e != p; p = e; }
+                    }
+                    corner c;
+                    c.v = vi > 0 ? (int)vi - 1 : (int)(V.size() / 3) + (int)vi;
+                    c.n = !has_n ? -1 : (ni > 0 ? (int)ni - 1 : (int)(N.size() / 3) + (int)ni);
+                    fc.push_back(c);
+                }
+                if (fc.size() >= 3) faces.push_back(fc);
+            }
+        }
+        double lo[3] = {infinity, infinity, infinity}, hi[3] = {-infinity, -infinity, -infinity};
+        for (size_t i = 0; i + 2 < V.size(); i += 3)
+            for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], V[i + k]); hi[k] = std::fmax(hi[k], V[i + k]); }
+        const vec3 off((lo[0] + hi[0]) / 2.0, lo[1], (lo[2] + hi[2]) / 2.0);
+        auto vert = [&](int i) { return point3((V[3 * i + 0] - off.x()) * scale, (V[3 * i + 1] - off.y()) * scale, (V[3 * i + 2] - off.z()) * scale); };
+        auto norm = [&](int i) { return vec3(N[3 * i + 0], N[3 * i + 1], N[3 * i + 2]); };
+        auto valid = [&](const corner& c) { return c.v >= 0 && (size_t)(3 * c.v + 2) < V.size(); };
+        auto emit = [&](const corner& a, const corner& b, const corner& c) {
+            if (!valid(a) || !valid(b) || !valid(c)) return;
+            point3 v0 = vert(a.v), v1 = vert(b.v), v2 = vert(c.v);
+            vec3 n0, n1, n2;
+            if (a.n >= 0 && b.n >= 0 && c.n >= 0 && (size_t)(3 * std::max(a.n, std::max(b.n, c.n)) + 2) < N.size()) { n0 = norm(a.n); n1 = norm(b.n); n2 = norm(c.n); }
+            else n0 = n1 = n2 = unit_vector(cross(v1 - v0, v2 - v0));
+            tris.push_back(make_shared<triangle>(v0, v1, v2, n0, n1, n2, mat));
+            bbox = aabb(bbox, tris.back()->bounding_box());
+        };
+        for (const auto& fc : faces) {
+            if (fc.size() == 3) emit(fc[0], fc[1], fc[2]);
+            else if (fc.size() == 4 && valid(fc[0]) && valid(fc[1]) && valid(fc[2]) && valid(fc[3])) {
+                const float* a = &V[3 * fc[0].v]; const float* b = &V[3 * fc[1].v]; const float* c = &V[3 * fc[2].v]; const float* d = &V[3 * fc[3].v];
+                const float e02x = c[0] - a[0], e02y = c[1] - a[1], e02z = c[2] - a[2];
+                const float e13x = d[0] - b[0], e13y = d[1] - b[1], e13z = d[2] - b[2];
+                const float s02 = e02x * e02x + e02y * e02y + e02z * e02z, s13 = e13x * e13x + e13y * e13y + e13z * e13z;
+                if (s02 < s13) { emit(fc[0], fc[1], fc[2]); emit(fc[0], fc[2], fc[3]); }
+                else { emit(fc[0], fc[1], fc[3]); emit(fc[1], fc[2], fc[3]); }
+            } else {
+                for (size_t k = 1; k + 1 < fc.size(); k++) emit(fc[0], fc[k], fc[k + 1]);
+            }
+        }
+        std::cout << "Model: " << filename << " loaded (" << tris.size() << " triangles)." << std::endl;
+    }
+    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("model::hit"); }
+    aabb bounding_box() const override { return bbox; }
+    void set_material(std::shared_ptr<material> m) { mat = m; }   // like the reference's: does not re-material existing triangles
+    void flatten(zenith::scene_builder& b) const override { for (const auto& t : tris) t->flatten(b); }
+    size_t triangle_count() const { return tris.size(); }
+private:
+    std::vector<shared_ptr<triangle>> tris;
+    shared_ptr<material> mat;
+    aabb bbox;
 };
 
 // ---- environment.hpp ---------------------------------------------------------------------------------

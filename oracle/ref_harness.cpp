@@ -2,6 +2,7 @@
 //
 // Drives the GENUINE reference arithmetic from /root/reference (headers are #included by path at build
 // time, in this container only; nothing of them is copied into the repo):
+//   model (OBJ ingest through the vendored tiny_obj_loader)   model.hpp:12-107
 //   world.hit          bvh.hpp:46-54,112-118  aabb.hpp:44-66  sphere.hpp:18-64  triangle.hpp:17-82
 //                      cube.hpp:44-142  constant_medium.hpp:39-77  translate/rotate_*/scale/material_instance
 //   scatter / emitted  material.hpp:74-96,129-151,192-224,261-263  constant_medium.hpp:14-18
@@ -43,6 +44,7 @@
 #include "scale.hpp"
 #include "material_instance.hpp"
 #include "bvh.hpp"
+#include "model.hpp"
 #include "environment.hpp"
 
 // ---- hooks for scenes/zr_scenes.inc ------------------------------------------------------------

@@ -508,7 +508,7 @@ struct Scene {
         for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
             double x = i ? in.hi[0] : in.lo[0], y = j ? in.hi[1] : in.lo[1], z = k ? in.hi[2] : in.lo[2];
             double t[3] = {x, y, z};
-            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x + s * z; t[2] = -s * x + co * z; }
+            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x - s * z; t[2] = s * x + co * z; }  // true object->world map (rotate_y.hpp:63-64), not the ctor's inverse
             else if (op.kind == ZR_OP_ROTATE_X) { t[1] = co * y - s * z; t[2] = s * y + co * z; }
             else { t[0] = co * x - s * y; t[1] = s * x + co * y; }
             for (int q = 0; q < 3; q++) { b.lo[q] = std::fmin(b.lo[q], t[q]); b.hi[q] = std::fmax(b.hi[q], t[q]); }

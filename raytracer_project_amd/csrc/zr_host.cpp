@@ -187,7 +187,10 @@ struct Boxer {
         for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
             double x = i ? in.hi[0] : in.lo[0], y = j ? in.hi[1] : in.lo[1], z = k ? in.hi[2] : in.lo[2];
             double t[3] = {x, y, z};
-            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x + sn * z; t[2] = -sn * x + co * z; }
+            // rotate_y.hpp:26-27 builds its box with the INVERSE rotation (+sin) although hit() maps object points with
+            // (cos x - sin z, sin x + cos z) (rotate_y.hpp:63-64): for children that are not symmetric about the y axis the
+            // reference's box misses real geometry and what gets culled depends on its random tree.  Bound the true geometry.
+            if (op.kind == ZR_OP_ROTATE_Y) { t[0] = co * x - sn * z; t[2] = sn * x + co * z; }
             else if (op.kind == ZR_OP_ROTATE_X) { t[1] = co * y - sn * z; t[2] = sn * y + co * z; }
             else { t[0] = co * x - sn * y; t[1] = sn * x + co * y; }
             for (int q = 0; q < 3; q++) { b.lo[q] = std::fmin(b.lo[q], t[q]); b.hi[q] = std::fmax(b.hi[q], t[q]); }

@@ -35,6 +35,7 @@ TILES = {
     "mix1_full": ("mix1", 0, 0, 96, 64, 0, False, []),
     "mix2_full": ("mix2", 0, 0, 96, 64, 0, False, []),
     "mix0_tile": ("mix0", 30, 20, 16, 16, 0, True, []),
+    "mesh0_full": ("mesh0", 0, 0, 96, 64, 0, False, []),            # OBJ ingest through `model`
 }
 TRACES = {
     # name -> (scene, rays, seed, probe-box clamp lo, hi, extra scene args)
@@ -42,6 +43,7 @@ TRACES = {
     "trace_cfg2": ("cfg2", 2048, 12, -12, 12, []),
     "trace_cfg5": ("cfg5", 2048, 13, -30, 600, []),
     "trace_cfg3_small": ("cfg3", 2048, 14, -4, 4, [200, 20, 256, 128]),
+    "trace_mesh0": ("mesh0", 4096, 15, -3, 4, []),
 }
 
 

@@ -66,6 +66,7 @@ def test_no_cpu_fallback(built):
     ("cfg3", (100, 10, 64, 32), dict(n_spheres=1, n_tris=2000, n_objects=2001, n_materials=2)),
     ("cfg5", (), dict(n_spheres=2, n_cubes=7, n_media=1, n_objects=9)),
     ("mix0", (), dict(n_spheres=13, n_tris=5, n_cubes=2, n_media=2, n_objects=20)),
+    ("mesh0", (), dict(n_spheres=2, n_tris=60 * 12 * 2 + 2 * 13, n_objects=2 + 60 * 12 * 2 + 2 * 13)),  # OBJ: 720 quads; box = 6 quads + 1 triangle
 ])
 def test_dropin_scene_api_flattens(name, args, expect, built):
     ds = demo_scene(name, args)
