@@ -907,6 +907,7 @@ public:
     bool use_denoiser = false;
     bool use_albedo_buffer = false, use_normal_buffer = false, use_z_depth_buffer = false, use_reflection = false, use_refraction = false;
     std::vector<color> render_accumulator;
+    std::vector<color> albedo_buffer, normal_buffer, z_depth_buffer;  // first-hit passes (camera.hpp:81-83), filled when their flag is set
     std::atomic<int> lines_rendered{0};
     uint64_t seed = 0x5EED0000ull;  // extension: the reference cannot be seeded (common.hpp:30-31)
     int device = 0;                 // extension: HIP device ordinal
@@ -914,11 +915,14 @@ public:
 
     void reset_accumulator() {  // camera.hpp:209-233
         render_accumulator.assign((size_t)image_width * image_height, color(0, 0, 0));
+        albedo_buffer.assign(render_accumulator.size(), color(0, 0, 0));
+        normal_buffer.assign(render_accumulator.size(), color(0, 0, 0));
+        z_depth_buffer.assign(render_accumulator.size(), color(0, 0, 0));
         current_samples_count = 0; lines_rendered = 0;
     }
 
     // camera.hpp:236.  Blocking; fills render_accumulator (mean radiance, row-major, idx = j*W + i).
-    void render(const hittable& world, const EnvironmentSettings& env, const post_processor&, std::atomic<bool>& render_flag) {
+    void render(const hittable& world, const EnvironmentSettings& env, const post_processor& post, std::atomic<bool>& render_flag) {
         static_assert(sizeof(std::atomic<bool>) == 1 && sizeof(std::atomic<int>) == sizeof(int), "flag layout");
         if (image_width < 1) image_width = 1;
         if (image_height < 1) image_height = 1;
@@ -943,6 +947,16 @@ public:
             rc = zr_render(ctx, sc, &zc, &zenv, seed, nullptr, 0, reinterpret_cast<double*>(render_accumulator.data()),
                            reinterpret_cast<volatile const uint8_t*>(&render_flag), reinterpret_cast<volatile int*>(&lines_rendered));
             zr_get_counters(ctx, &last_counters);
+            if (rc == ZR_OK && (use_albedo_buffer || use_normal_buffer || use_z_depth_buffer)) {
+                const size_t npx = (size_t)image_width * image_height;
+                if (use_albedo_buffer) albedo_buffer.assign(npx, color(0, 0, 0));
+                if (use_normal_buffer) normal_buffer.assign(npx, color(0, 0, 0));
+                if (use_z_depth_buffer) z_depth_buffer.assign(npx, color(0, 0, 0));
+                zr_aov_params ap{post.z_depth_max_dist};
+                rc = zr_render_aov(ctx, sc, &zc, seed, nullptr, &ap, use_albedo_buffer ? reinterpret_cast<double*>(albedo_buffer.data()) : nullptr,
+                                   use_normal_buffer ? reinterpret_cast<double*>(normal_buffer.data()) : nullptr,
+                                   use_z_depth_buffer ? reinterpret_cast<double*>(z_depth_buffer.data()) : nullptr);
+            }
         }
         if (rc != ZR_OK && rc != ZR_E_CANCELLED) std::cerr << "[zenith] render failed: " << zr_last_error() << "\n";
         if (sc) zr_scene_destroy(sc);

@@ -248,6 +248,19 @@ int zr_render(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_
 int zr_render_device(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed,
                      const zr_region* region, int collect_counters,
                      void* d_out_rgb, void* hip_stream);
+/* ---- first-hit AOV passes: the albedo / normal / z-depth part of render_rows (camera.hpp:433, 464-488, 521-541) ---- */
+/* For the first min(clamp(spp / 8, 64, 1024), spp) samples of every pixel the primary hit contributes
+ *   albedo  += rec.mat->get_albedo(rec)                       (material.hpp:29-31,99-102,154-156,226-229,266-275)
+ *   normal  += (unit(rec.normal) . (u, v, w) + 1) / 2          camera space; a miss adds (0.5, 0.5, 1.0)
+ *   z-depth += 1 - clamp(rec.t / z_depth_max_dist, 0, 1)       as a grey colour
+ * and the sums are divided by the number of those samples.  Same seeds and the same primary rays as zr_render.
+ * Output buffers are W*H*3 doubles in host memory, laid out like out_rgb; a NULL buffer skips that pass. */
+typedef struct zr_aov_params {
+    double z_depth_max_dist; /* post_processor::z_depth_max_dist */
+} zr_aov_params;
+int zr_render_aov(zr_ctx*, const zr_scene*, const zr_camera*, uint64_t seed, const zr_region* region, const zr_aov_params*,
+                  double* out_albedo, double* out_normal, double* out_zdepth);
+
 /* counters + device time of the last render on this context (synchronises the context's stream) */
 int zr_get_counters(zr_ctx*, zr_counters*);
 /* drains the log of render-kernel launch durations (ms, measured with HIP events on the launch stream) recorded

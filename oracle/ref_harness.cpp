@@ -221,6 +221,22 @@ struct ref_camera {
         return L;
     }
 
+    // first-hit AOVs of one primary sample: camera.hpp:464-488 (hit) and 521-525 (miss)
+    void aov_sample(int i, int j, const hittable& world, double zmax, color& albedo, color& normal, color& zdepth) const {
+        ray r = get_ray(i, j);
+        hit_record rec;
+        if (world.hit(r, interval(0.001, infinity), rec)) {
+            albedo += rec.mat->get_albedo(rec);
+            vec3 n = unit_vector(rec.normal);
+            double nx = dot(n, u), ny = dot(n, v), nz = dot(n, w);
+            normal += color((nx + 1.0) * 0.5, (ny + 1.0) * 0.5, (nz + 1.0) * 0.5);
+            double zd = 1.0 - std::clamp(rec.t / zmax, 0.0, 1.0);
+            zdepth += color(zd, zd, zd);
+        } else {
+            normal += color(0.5, 0.5, 1.0);
+        }
+    }
+
     // one primary sample of pixel (i, j): the body of the sample loop, camera.hpp:455-461,520
     color sample(int i, int j, const hittable& world, const EnvironmentSettings& env) const {
         ray r = get_ray(i, j);
@@ -336,6 +352,7 @@ static int usage() {
                  "  zenith_ref tile   <scene> <x0> <y0> <w> <h> <spp|0> <threads> <out_prefix> [per_sample=0] [a0 a1 a2 a3]\n"
                  "  zenith_ref time   <scene> <xstep> <ystep> <spp|0> <threads> [a0 a1 a2 a3]\n"
                  "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> <clamp_lo> <clamp_hi> [a0 a1 a2 a3]\n"
+                 "  zenith_ref aov    <scene> <x0> <y0> <w> <h> <zmax> <out_prefix> - [a0 a1 a2 a3]\n"
                  "  zenith_ref texels <w> <h> <out.npy>\n");
     return 2;
 }
@@ -366,6 +383,45 @@ int main(int argc, char** argv) {
                     argv[2], x0, y0, w, h, spp, cam.c.max_depth, cam.c.image_width, cam.c.image_height,
                     (unsigned long long)b.s.seed, (unsigned long long)r.segments, (unsigned long long)r.draws,
                     (unsigned long long)r.medium_draws, b.s.world.objects.size(), b.build_s, r.seconds);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "aov" && argc >= 10) {
+        // zenith_ref aov <scene> <x0> <y0> <w> <h> <zmax> <out_prefix> <unused> [a0..a3]: albedo / normal / z-depth tiles
+        built_scene b;
+        if (!build(b, argv[2], iarg(10, 0), iarg(11, 0), iarg(12, 0), iarg(13, 0))) return usage();
+        int x0 = iarg(3, 0), y0 = iarg(4, 0), w = iarg(5, 1), h = iarg(6, 1);
+        double zmax = std::atof(argv[7]);
+        std::string out = argv[8];
+        ref_camera cam; cam.c = b.s.cam; cam.initialize();
+        const int spp = cam.c.samples_per_pixel;
+        const int aux_sample = std::clamp(spp / 8, 64, 1024);   // camera.hpp:433
+        const int actual = std::min(aux_sample, spp);            // camera.hpp:535
+        probe_world world(*b.bvh);
+        std::vector<double> A((size_t)w * h * 3), N((size_t)w * h * 3), Z((size_t)w * h * 3);
+        for (int jj = 0; jj < h; jj++)
+            for (int ii = 0; ii < w; ii++) {
+                int i = x0 + ii, j = y0 + jj;
+                color a(0, 0, 0), n(0, 0, 0), z(0, 0, 0);
+                for (int s2 = 0; s2 < spp; s2++) {
+                    if (!(s2 < aux_sample)) break;
+                    zr_oracle_seed(b.s.seed, (uint64_t)j * cam.c.image_width + i, (uint64_t)s2);
+                    probe_world::sample_segments() = 0;
+                    cam.aov_sample(i, j, world, zmax, a, n, z);
+                }
+                double sc = 1.0 / actual;
+                color am = a * sc, nm = n * sc, zm = z * sc;
+                size_t o = ((size_t)jj * w + ii) * 3;
+                A[o] = am.x(); A[o + 1] = am.y(); A[o + 2] = am.z();
+                N[o] = nm.x(); N[o + 1] = nm.y(); N[o + 2] = nm.z();
+                Z[o] = zm.x(); Z[o + 1] = zm.y(); Z[o + 2] = zm.z();
+            }
+        write_npy(out + "_albedo.npy", "<f8", {(size_t)h, (size_t)w, 3}, A.data(), A.size() * 8);
+        write_npy(out + "_normal.npy", "<f8", {(size_t)h, (size_t)w, 3}, N.data(), N.size() * 8);
+        write_npy(out + "_zdepth.npy", "<f8", {(size_t)h, (size_t)w, 3}, Z.data(), Z.size() * 8);
+        std::printf("{\"scene\": \"%s\", \"x0\": %d, \"y0\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"aux\": %d, \"zmax\": %.17g, \"seed\": %llu}\n",
+                    argv[2], x0, y0, w, h, spp, actual, zmax, (unsigned long long)b.s.seed);
         cleanup(b);
         return 0;
     }

@@ -182,6 +182,17 @@ struct Scene {
         return V3(0, 0, 0);
     }
 
+    V3 albedo(const Rec& rec) const {  // material::get_albedo, material.hpp:29-31,99-102,154-156,226-229,266-275
+        const zr_material& m = d.materials[rec.mat];
+        switch (m.kind) {
+            case ZR_MAT_LAMBERTIAN:
+            case ZR_MAT_METAL: return tex_value(m.tex, rec.u, rec.v, rec.p);
+            case ZR_MAT_DIELECTRIC: return V3(1.0, 1.0, 1.0);
+            case ZR_MAT_LIGHT: { V3 c = tex_value(m.tex, rec.u, rec.v, rec.p); return V3(std::fmin(c.x(), 1.0), std::fmin(c.y(), 1.0), std::fmin(c.z(), 1.0)); }
+            default: return V3(0, 0, 0);
+        }
+    }
+
     bool scatter(const Ray& rin, const Rec& rec, V3& att, Ray& out, Rng& g) const {
         const zr_material& m = d.materials[rec.mat];
         switch (m.kind) {
@@ -828,6 +839,43 @@ int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t
             ctr->media_tested += c.med; ctr->hits += c.hits; ctr->rng_draws += c.draws;
         }
     }
+    return ZR_OK;
+}
+
+// first-hit AOVs (camera.hpp:433, 464-488, 521-541); outputs are region-sized h*w*3 (any may be NULL)
+int zro_render_aov(void* scene, const zr_camera* cam_in, uint64_t seed, const zr_region* region, double zmax, double* albedo, double* normal,
+                   double* zdepth) {
+    const Scene& sc = *(Scene*)scene;
+    Cam cam; cam.c = *cam_in; cam.initialize();
+    const int W = cam.c.image_width, spp = cam.c.samples_per_pixel;
+    const int x0 = region->x0, y0 = region->y0, w = region->w, h = region->h;
+    const int aux_sample = std::clamp(spp / 8, 64, 1024);
+    const int actual = std::min(aux_sample, spp);
+    for (int jj = 0; jj < h; jj++)
+        for (int ii = 0; ii < w; ii++) {
+            const int i = x0 + ii, j = y0 + jj;
+            V3 a(0, 0, 0), n(0, 0, 0), z(0, 0, 0);
+            for (int s = 0; s < spp && s < aux_sample; s++) {
+                Rng g; g.key = zr_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s);
+                Ray r = cam.get_ray(i, j, g);
+                Rec rec;
+                if (sc.world_hit(r, 0.001, kInf, rec, g, nullptr)) {
+                    a = a + sc.albedo(rec);
+                    V3 un = unit(rec.n);
+                    n = n + V3((dot(un, cam.u) + 1.0) * 0.5, (dot(un, cam.v) + 1.0) * 0.5, (dot(un, cam.w) + 1.0) * 0.5);
+                    double zd = 1.0 - clampd(rec.t / zmax, 0.0, 1.0);
+                    z = z + V3(zd, zd, zd);
+                } else {
+                    n = n + V3(0.5, 0.5, 1.0);
+                }
+            }
+            const double scl = 1.0 / actual;
+            const size_t o = ((size_t)jj * w + ii) * 3;
+            V3 am = a * scl, nm = n * scl, zm = z * scl;
+            if (albedo) { albedo[o] = am.x(); albedo[o + 1] = am.y(); albedo[o + 2] = am.z(); }
+            if (normal) { normal[o] = nm.x(); normal[o + 1] = nm.y(); normal[o + 2] = nm.z(); }
+            if (zdepth) { zdepth[o] = zm.x(); zdepth[o + 1] = zm.y(); zdepth[o + 2] = zm.z(); }
+        }
     return ZR_OK;
 }
 

@@ -85,6 +85,10 @@ class Counters(C.Structure):
                 + 48 * self.cubes_tested + 76 * self.hits)
 
 
+class AovParams(C.Structure):
+    _fields_ = [("z_depth_max_dist", C.c_double)]
+
+
 class Hit(C.Structure):
     _fields_ = [("p", C.c_double * 3), ("normal", C.c_double * 3), ("tangent", C.c_double * 3),
                 ("bitangent", C.c_double * 3), ("t", C.c_double), ("u", C.c_double), ("v", C.c_double),
@@ -116,7 +120,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace",
 ]
 
@@ -150,6 +154,7 @@ def load():
     lib.zr_scene_stats.argtypes = [vp, C.POINTER(u64 * 4)]
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
+    lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.zr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), i32]
     lib.zr_trace.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, u64, u64, C.c_uint32, vp]
@@ -283,6 +288,16 @@ class Scene:
         _check(self.lib.zr_render(self.ctx._c, self._s, C.byref(camera), C.byref(env), C.c_uint64(seed), rp,
                                   1 if count else 0, out.ctypes.data, None, None))
         return out
+
+    def render_aov(self, camera, seed, z_depth_max_dist, region=None):
+        """first-hit albedo / normal / z-depth passes (camera.hpp:464-488): three (H, W, 3) float64 frames"""
+        h, w = camera.image_height, camera.image_width
+        outs = [np.zeros((h, w, 3), dtype=np.float64) for _ in range(3)]
+        ap = AovParams(float(z_depth_max_dist))
+        rp = C.byref(region) if region is not None else None
+        _check(self.lib.zr_render_aov(self.ctx._c, self._s, C.byref(camera), C.c_uint64(seed), rp, C.byref(ap),
+                                      outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data))
+        return outs
 
     def render_device(self, camera, env, seed, d_ptr, stream=0, region=None, count=False):
         rp = C.byref(region) if region is not None else None

@@ -481,6 +481,19 @@ __device__ inline V3 emitted(const DScene& sc, const Rec& rec) {  // material.hp
     return mk(0, 0, 0);
 }
 
+// material::get_albedo (material.hpp:29-31, 99-102, 154-156, 226-229, 266-275)
+__device__ inline V3 get_albedo(const DScene& sc, const Rec& rec) {
+    if (rec.mat >= sc.n_mats) return mk(0, 0, 0);
+    const zr_material& m = sc.mats[rec.mat];
+    switch (m.kind) {
+        case ZR_MAT_LAMBERTIAN:
+        case ZR_MAT_METAL: return tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+        case ZR_MAT_DIELECTRIC: return mk(1.0, 1.0, 1.0);
+        case ZR_MAT_LIGHT: { V3 c = tex_value(sc, m.tex, rec.u, rec.v, rec.p); return mk(fmin(c.x, 1.0), fmin(c.y, 1.0), fmin(c.z, 1.0)); }
+        default: return mk(0, 0, 0);  // isovolumetric keeps material's default
+    }
+}
+
 // returns false when the path ends (absorbed / light).  A null material (UB in the reference) absorbs.
 __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec, V3& att, Ray& out, Rng& g) {
     if (rec.mat >= sc.n_mats) return false;

@@ -947,6 +947,54 @@ int zr_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* 
     return ZR_OK;
 }
 
+int zr_render_aov(zr_ctx* c, const zr_scene* s, const zr_camera* cam, uint64_t seed, const zr_region* region, const zr_aov_params* ap,
+                  double* out_albedo, double* out_normal, double* out_zdepth) {
+    if (!c || !s || !cam || !ap) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_render_aov");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    if (!out_albedo && !out_normal && !out_zdepth) return ZR_OK;
+    HIP_OK(hipSetDevice(c->device));
+    Plan plan;
+    int rc = make_plan(*cam, region, plan);
+    if (rc) return rc;
+    zr::DCamera dc; make_camera(*cam, dc);
+    // camera basis u, v, w exactly as camera::initialize builds it (camera.hpp:380-382)
+    H3 w = unit(h3(cam->lookfrom) - h3(cam->lookat));
+    H3 u = unit(cross(h3(cam->vup), w));
+    H3 v = cross(w, u);
+    double uvw[9] = {u.x, u.y, u.z, v.x, v.y, v.z, w.x, w.y, w.z};
+    const int spp = dc.spp;
+    const int aux_sample = std::min(std::max(spp / 8, 64), 1024);   // std::clamp(spp / 8, 64, 1024), camera.hpp:433
+    const int aux = std::min(aux_sample, spp);                      // camera.hpp:535
+    const size_t npx = (size_t)plan.W * plan.H;
+    DevBuf<double> d_a, d_n, d_z;
+    if (out_albedo) { if ((rc = d_a.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_a.p, 0, npx * 24, c->stream)); }
+    if (out_normal) { if ((rc = d_n.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_n.p, 0, npx * 24, c->stream)); }
+    if (out_zdepth) { if ((rc = d_z.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_z.p, 0, npx * 24, c->stream)); }
+    std::vector<int32_t> tiles = plan.tiles;
+    if ((rc = c->d_tiles.upload(tiles))) return rc;
+    zr::WorkDesc wd;
+    wd.tiles = c->d_tiles.p; wd.n_tiles = (int32_t)tiles.size(); wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
+    wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
+    wd.lanes_per_pixel = 64; while (wd.lanes_per_pixel > aux) wd.lanes_per_pixel >>= 1;
+    HIP_OK(zr::launch_aov(s->ds, dc, seed, wd, aux, ap->z_depth_max_dist, uvw, d_a.p, d_n.p, d_z.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<double> frame(npx * 3);
+    auto copy_out = [&](DevBuf<double>& d, double* out) -> int {
+        if (!out) return ZR_OK;
+        HIP_OK(hipMemcpy(frame.data(), d.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int32_t t : plan.tiles) {
+            int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+            int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+            for (int y = ya; y < yb; y++)
+                if (xb > xa) std::memcpy(out + ((size_t)y * plan.W + xa) * 3, frame.data() + ((size_t)y * plan.W + xa) * 3, (size_t)(xb - xa) * 3 * sizeof(double));
+        }
+        return ZR_OK;
+    };
+    if ((rc = copy_out(d_a, out_albedo)) || (rc = copy_out(d_n, out_normal)) || (rc = copy_out(d_z, out_zdepth))) return rc;
+    return ZR_OK;
+}
+
 int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (!c || !out) return fail(ZR_E_INVALID, "null argument");
     HIP_OK(hipSetDevice(c->device));

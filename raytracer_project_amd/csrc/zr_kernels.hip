@@ -122,6 +122,61 @@ __global__ __launch_bounds__(ZR_BLOCK) void render_pixels(DScene sc, DCamera cam
     }
 }
 
+// first-hit AOVs (camera.hpp:433, 464-488, 521-541): same pixel-group layout as render_pixels, primary rays only
+__global__ __launch_bounds__(ZR_BLOCK) void aov_pixels(DScene sc, DCamera cam, uint64_t seed, WorkDesc wd, int aux, double zmax, double3 cu, double3 cv,
+                                                        double3 cw, double* __restrict__ out_albedo, double* __restrict__ out_normal,
+                                                        double* __restrict__ out_zdepth) {
+    __shared__ uint32_t lds_stack[ZR_STACK_DEPTH * ZR_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const int L = wd.lanes_per_pixel;
+    const int groups_per_block = ZR_BLOCK / L;
+    const int group = threadIdx.x / L, lane_in_group = threadIdx.x % L;
+    const long long q = (long long)blockIdx.x * groups_per_block + group;
+    const int tpix = wd.tile_size * wd.tile_size;
+    bool active = q < (long long)wd.n_tiles * tpix;
+    int px = 0, py = 0;
+    if (active) {
+        int tile = wd.tiles[q / tpix];
+        int local = (int)(q % tpix);
+        px = (tile % wd.tiles_x) * wd.tile_size + local % wd.tile_size;
+        py = (tile / wd.tiles_x) * wd.tile_size + local / wd.tile_size;
+        active = px >= wd.x0 && px < wd.x1 && py >= wd.y0 && py < wd.y1;
+    }
+    V3 a = mk(0, 0, 0), n = mk(0, 0, 0), z = mk(0, 0, 0);
+    Counters ctr = {0, 0, 0, 0, 0};
+    if (active) {
+        const uint64_t pixel = (uint64_t)py * (uint64_t)cam.W + (uint64_t)px;
+        for (int s = lane_in_group; s < aux; s += L) {
+            Rng g; g.key = zr_stream_key(seed, pixel, (uint64_t)s); g.k = 0; g.bounce = 0;
+            Ray r = camera_ray(cam, px, py, g);
+            double t; uint32_t kind, idx;
+            if (closest_hit<false>(sc, r, 0.001, g, stack, ZR_BLOCK, t, kind, idx, ctr)) {
+                Rec rec;
+                object_rec(sc, kind, idx, r, t, rec);
+                a = a + get_albedo(sc, rec);
+                V3 un = unit(rec.n);
+                n = n + mk((dot(un, mk(cu.x, cu.y, cu.z)) + 1.0) * 0.5, (dot(un, mk(cv.x, cv.y, cv.z)) + 1.0) * 0.5, (dot(un, mk(cw.x, cw.y, cw.z)) + 1.0) * 0.5);
+                double zd = 1.0 - clampd(rec.t / zmax, 0.0, 1.0);
+                z = z + mk(zd, zd, zd);
+            } else {
+                n = n + mk(0.5, 0.5, 1.0);
+            }
+        }
+    }
+    for (int m = 1; m < L; m <<= 1) {
+        a.x += shfl_xor_f64(a.x, m); a.y += shfl_xor_f64(a.y, m); a.z += shfl_xor_f64(a.z, m);
+        n.x += shfl_xor_f64(n.x, m); n.y += shfl_xor_f64(n.y, m); n.z += shfl_xor_f64(n.z, m);
+        z.x += shfl_xor_f64(z.x, m); z.y += shfl_xor_f64(z.y, m); z.z += shfl_xor_f64(z.z, m);
+    }
+    if (active && lane_in_group == 0) {
+        const double scale = 1.0 / aux;  // camera.hpp:535-536
+        const size_t o = ((size_t)py * cam.W + px) * 3;
+        if (out_albedo) { out_albedo[o] = a.x * scale; out_albedo[o + 1] = a.y * scale; out_albedo[o + 2] = a.z * scale; }
+        if (out_normal) { out_normal[o] = n.x * scale; out_normal[o + 1] = n.y * scale; out_normal[o + 2] = n.z * scale; }
+        if (out_zdepth) { out_zdepth[o] = z.x * scale; out_zdepth[o + 1] = z.y * scale; out_zdepth[o + 2] = z.z * scale; }
+    }
+}
+
 // known-answer kernel: world.hit(r, interval(tmin, tmax), rec) for a batch of rays, one ray per thread
 __global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* __restrict__ rays, size_t n, double tmin, double tmax,
                                                         uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* __restrict__ out) {
@@ -160,6 +215,18 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     dim3 grid((unsigned)blocks), block(ZR_BLOCK);
     if (count) hipLaunchKernelGGL(render_pixels<true>, grid, block, 0, stream, sc, cam, env, seed, wd, out, gctr);
     else hipLaunchKernelGGL(render_pixels<false>, grid, block, 0, stream, sc, cam, env, seed, wd, out, gctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const WorkDesc& wd, int aux, double zmax, const double* uvw9,
+                      double* out_albedo, double* out_normal, double* out_zdepth, hipStream_t stream) {
+    const int groups_per_block = ZR_BLOCK / wd.lanes_per_pixel;
+    const long long pixels = (long long)wd.n_tiles * wd.tile_size * wd.tile_size;
+    const long long blocks = (pixels + groups_per_block - 1) / groups_per_block;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    double3 cu = make_double3(uvw9[0], uvw9[1], uvw9[2]), cv = make_double3(uvw9[3], uvw9[4], uvw9[5]), cw = make_double3(uvw9[6], uvw9[7], uvw9[8]);
+    hipLaunchKernelGGL(aov_pixels, dim3((unsigned)blocks), dim3(ZR_BLOCK), 0, stream, sc, cam, seed, wd, aux, zmax, cu, cv, cw, out_albedo, out_normal, out_zdepth);
     return hipGetLastError();
 }
 

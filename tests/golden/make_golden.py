@@ -47,6 +47,15 @@ TRACES = {
 }
 
 
+# first-hit AOV tiles: name -> (scene, x0, y0, w, h, z_depth_max_dist, extra scene args)
+AOVS = {
+    "aov_mix0": ("mix0", 0, 0, 96, 64, 20.0, []),
+    "aov_mix1": ("mix1", 8, 8, 64, 40, 12.0, []),
+    "aov_cfg2": ("cfg2", 560, 280, 48, 32, 20.0, []),
+    "aov_mesh0": ("mesh0", 0, 0, 96, 64, 9.0, []),
+}
+
+
 def run(*args):
     p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -77,6 +86,15 @@ def main():
             meta["scene_args"] = extra
             np.savez_compressed(os.path.join(HERE, name + ".npz"), rays=np.load(pre + "_rays.npy"),
                                 recs=np.load(pre + "_recs.npy"), meta=np.array(json.dumps(meta)))
+            print(name, meta)
+        for name, (scene, x0, y0, w, h, zmax, extra) in AOVS.items():
+            if want and name not in want and scene not in want:
+                continue
+            pre = os.path.join(tmp, name)
+            meta = run("aov", scene, x0, y0, w, h, zmax, pre, "-", *extra)
+            meta["scene_args"] = extra
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), albedo=np.load(pre + "_albedo.npy"), normal=np.load(pre + "_normal.npy"),
+                                zdepth=np.load(pre + "_zdepth.npy"), meta=np.array(json.dumps(meta)))
             print(name, meta)
         if not want or "texels" in want:
             out = os.path.join(tmp, "texels.npy")
