@@ -121,7 +121,7 @@ CAPI_SYMBOLS = [
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
     "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_get_counters",
-    "zr_get_kernel_times", "zr_trace",
+    "zr_get_kernel_times", "zr_trace", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
 ]
 
 
@@ -158,6 +158,10 @@ def load():
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.zr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), i32]
     lib.zr_trace.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, u64, u64, C.c_uint32, vp]
+    lib.zr_comm_unique_id.argtypes = [vp]
+    lib.zr_comm_create.restype = vp; lib.zr_comm_create.argtypes = [vp, i32, i32, vp]
+    lib.zr_comm_reduce_frame.argtypes = [vp, vp, C.c_size_t, i32, vp]
+    lib.zr_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -414,6 +414,9 @@ double env_double(const char* name, double dflt) {
 extern "C" {
 
 int zr_abi_version(void) { return ZR_ABI_VERSION; }
+// helpers for zr_comm.cpp
+int zr_internal_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+int zr_internal_device(const zr_ctx* c) { return c ? c->device : 0; }
 const char* zr_last_error(void) { return g_err.c_str(); }
 
 zr_ctx* zr_create(int device_ordinal) {
@@ -827,9 +830,15 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
     HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
-    if (c->variant == 2 && dc.max_depth <= 250 && !s->quad_ok)
-        return fail(ZR_E_INVALID, "kernel variant 2 needs < 16 Mi primitives per kind and leaves of <= 16 primitives; set ZR_KERNEL=1");
-    if (c->variant == 2 && dc.max_depth <= 250) {
+    // the streaming pipeline packs bounce counters into 8 bits, work units into 32 bits and leaf references into 24 + 4
+    // bits; frames or scenes beyond that are rendered by the pixel-group megakernel below (slower, same results)
+    uint64_t stream_units = 0;
+    for (int32_t t : plan.tiles) {
+        int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+        int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+        if (xb > xa && yb > ya) stream_units += (uint64_t)(xb - xa) * (yb - ya) * (uint64_t)dc.spp;
+    }
+    if (c->variant == 2 && dc.max_depth <= 250 && s->quad_ok && stream_units <= 0xFFFFFFFFull && plan.W <= 65535 && plan.H <= 65535) {
         int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going);
         if (rows_done && r2 == ZR_OK) *rows_done = plan.H;
         return r2;

@@ -52,12 +52,17 @@ def test_no_cpu_fallback(built):
     ds = demo_scene("cfg1")
     with pytest.raises(capi.ZrError):
         ds.render_dropin(32, 18, 1)
-    # and nothing in the product package imports the oracle
+    # and nothing in the product package loads, links or imports the oracle
+    import subprocess
     for root, _, files in os.walk(os.path.join(ROOT, "raytracer_project_amd")):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
-                assert "oracle" not in open(os.path.join(root, f), errors="ignore").read().replace("the oracle harness", "").replace("oracle/", "").lower() \
-                    or f in ("zr_scenes_lib.cpp", "Makefile"), f"{f} mentions the oracle"
+            path = os.path.join(root, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                assert "import oracle" not in src and "from oracle" not in src and "zr_oracle" not in src, f"{f} uses the oracle"
+            if f.endswith(".so"):
+                needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+                assert "zr_oracle" not in needed, f"{f} links the oracle"
 
 
 @pytest.mark.parametrize("name,args,expect", [

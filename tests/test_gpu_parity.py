@@ -230,3 +230,21 @@ def test_aov_passes_match_reference(name, ctx):
     outside = np.ones(a.shape[:2], bool)
     outside[sl] = False
     assert not a[outside].any() and not n[outside].any() and not z[outside].any()
+
+
+def test_cxx_host_collective_single_rank(ctx):
+    """zr_comm_*: the RCCL reduce entry points a C++ host uses.  With one rank the reduce is the identity; this checks the
+    lazy librccl.so binding, communicator creation on the context's device and an in-place ncclReduce of doubles."""
+    import ctypes as C
+    import torch
+    lib = ctx.lib
+    uid = (C.c_ubyte * 128)()
+    assert lib.zr_comm_unique_id(uid) == 0, lib.zr_last_error()
+    comm = lib.zr_comm_create(ctx._c, 1, 0, uid)
+    assert comm, lib.zr_last_error()
+    frame = torch.arange(3 * 64 * 48, dtype=torch.float64, device="cuda").reshape(48, 64, 3) * 0.25
+    want = frame.clone()
+    assert lib.zr_comm_reduce_frame(comm, C.c_void_p(frame.data_ptr()), frame.numel(), 0, None) == 0, lib.zr_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(frame, want)
+    lib.zr_comm_destroy(comm)
