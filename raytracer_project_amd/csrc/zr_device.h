@@ -280,8 +280,8 @@ __device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, 
 }
 
 __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // triangle.hpp:40-79
-    const double* v = sc.tri_v + (size_t)idx * 9;
-    const double* nn = sc.tri_n + (size_t)idx * 9;
+    const double* v = sc.tri_s + (size_t)idx * 20;  // one record = everything the hit record needs
+    const double* nn = v + 9;
     V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
     V3 normal = cross(v1 - v0, v2 - v0);
     V3 p = at(r, t);
@@ -294,7 +294,7 @@ __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r
     V3 smooth = unit(w0 * ld3(nn) + u * ld3(nn + 3) + w_ * ld3(nn + 6));
     rec.t = t;
     rec.p = p;
-    rec.mat = sc.tri_mat[idx];
+    rec.mat = (uint32_t)__double_as_longlong(v[18]);
     set_face(rec, r.d, smooth);
     // u, v, tangent, bitangent are not written by triangle::hit: fresh-record values
     rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);

@@ -20,14 +20,30 @@ struct alignas(64) NodePair {
 };
 static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 
-// 4-wide node (128 B = one L2 line): the children's FP32 boxes as six float4 rows + links + leaf meta.  Walked by
-// the EXTEND kernel of variant 2: half as many dependent fetches per ray as the pair records, one line each.
-struct alignas(128) NodeQuad {
-    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    uint32_t child[4];  // as NodePair::child
-    uint32_t meta[4];   // as NodePair::meta; an unused slot is a leaf with count 0
+// 4-wide nodes of the EXTEND kernel (variant 2).
+//  * NodeQ, 64 bytes = four 16-byte loads per visit: the children's boxes are 8-bit quantised on the node's own
+//    grid: plane = origin[axis] + q * scale[axis] (as real numbers; the kernel never rounds it, see EXTEND), and the
+//    builder picks the q's so that this box CONTAINS the true box (lower planes rounded down, upper planes up).  Box tests were already conservative; a looser box only adds visits.
+//  * NodeF, plain FP32 boxes: the ROOT only.  It travels in the kernel arguments (scalar registers), so the first
+//    step of every ray costs no memory access, and it is the node where a grid hurts most (a ground sphere next to
+//    the mesh: the mesh's box on a 2000-unit grid swallowed the camera and every ray paid 2.4 extra visits).
+// Measured on MI355X (scripts/dev/randread.hip): a wave's divergent 16-byte loads cost the L1 about one clock per
+// lane and instruction, and a random record costs the fabric one request whatever its size.
+//   q[0..2] = lower x, y, z planes, q[3..5] = upper; byte c of each word belongs to child c.
+//   ref[c]: ZR_REF_EMPTY, an inner node's index, or ZR_REF_LEAF | kind << 28 | (count - 1) << 24 | first primitive.
+#define ZR_REF_LEAF 0x80000000u
+#define ZR_REF_EMPTY 0xFFFFFFFFu
+struct alignas(64) NodeQ {
+    float origin[3];
+    float scale[3];
+    uint32_t q[6];
+    uint32_t ref[4];
 };
-static_assert(sizeof(NodeQuad) == 128, "NodeQuad must be 128 bytes");
+static_assert(sizeof(NodeQ) == 64, "NodeQ must be 64 bytes");
+struct NodeF {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t ref[4];
+};
 
 struct DMedium {
     uint32_t btype, bindex, chain_first, chain_count;
@@ -38,12 +54,12 @@ struct DWrapped { uint32_t type, index, chain_first, chain_count; };
 
 struct DScene {
     const NodePair* nodes;
-    const NodeQuad* quads;
+    const NodeQ* quads;
     const double* spheres;      // 4 per sphere: cx cy cz max(0, r)
     const uint32_t* sphere_mat;
     const double* tri_v;        // 9 per triangle
-    const double* tri_n;        // 9 per triangle
-    const uint32_t* tri_mat;
+    const double* tri_s;        // shading record, 20 doubles (160 B, two 128-B lines at any 32-B phase) per triangle:
+                                // [0..8] vertices, [9..17] vertex normals, [18] low word = material id
     const double* cubes;        // 6 per cube: half extents, centre
     const uint32_t* cube_mat;
     const DMedium* media;
@@ -53,7 +69,8 @@ struct DScene {
     const zr_texture* texs;
     const unsigned char* texels;
     uint32_t n_mats;
-    uint32_t root_meta;  // unused (root is pair 0)
+    uint32_t pad_;
+    NodeF root;          // variant 2: the root of the 4-wide tree
 };
 
 struct DCamera {

@@ -79,7 +79,7 @@ struct DevBuf {
 struct zr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;        // second stream of the streaming pipeline (half pool B)
+    hipStream_t sub[ST_MAX_POOLS] = {};   // internal streams of the streaming pipeline's sub-pools 1..K-1 (sub[0] unused)
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
@@ -95,7 +95,7 @@ struct zr_ctx {
     DevBuf<unsigned char> d_st_overflow;
     int st_blocks = 0;
     uint32_t st_slots = 0;
-    int st_overlap = -1;                  // two half pools half a round apart on two streams: 0 off, 1 on, -1 auto
+    int st_pools = -1;                    // sub-pools staggered on separate streams: 1 = one pool, -1 = auto
     hipEvent_t st_event = nullptr;
     unsigned int* h_active = nullptr;     // pinned
     std::vector<int32_t> pix_key;         // plan the cached pixel list was built for
@@ -128,10 +128,10 @@ struct zr_scene {
     // device
     bool committed = false;
     DevBuf<zr::NodePair> d_nodes;
-    DevBuf<zr::NodeQuad> d_quads;
+    DevBuf<zr::NodeQ> d_quads;
     bool quad_ok = true;          // leaf references fit the EXTEND kernel's 32-bit stack entries
-    DevBuf<double> d_spheres, d_tri_v, d_tri_n, d_cubes;
-    DevBuf<uint32_t> d_sphere_mat, d_tri_mat, d_cube_mat;
+    DevBuf<double> d_spheres, d_tri_v, d_tri_s, d_cubes;
+    DevBuf<uint32_t> d_sphere_mat, d_cube_mat;
     DevBuf<zr::DMedium> d_media;
     DevBuf<zr::DWrapped> d_wrapped;
     DevBuf<zr_xform_op> d_ops;
@@ -265,11 +265,11 @@ struct Flattener {
     const std::vector<zr_object>& objs;
     const zr::BuildResult& br;
     std::vector<zr::NodePair> pairs;
-    std::vector<zr::NodeQuad> quads;
+    std::vector<zr::NodeQ> quads;
     std::vector<uint32_t> leaf_first;  // per build node: device index of a leaf's first primitive
     int quad_depth = 0;
-    std::vector<double> spheres, tri_v, tri_n, cubes;
-    std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
+    std::vector<double> spheres, tri_v, tri_s, cubes;
+    std::vector<uint32_t> sphere_mat, cube_mat;
     std::vector<zr::DMedium> media;
     std::vector<zr::DWrapped> wrapped;
 
@@ -283,9 +283,12 @@ struct Flattener {
             }
             case ZR_PRIM_TRIANGLE: {
                 tri_v.insert(tri_v.end(), &s.tri_v[(size_t)idx * 9], &s.tri_v[(size_t)idx * 9] + 9);
-                tri_n.insert(tri_n.end(), &s.tri_n[(size_t)idx * 9], &s.tri_n[(size_t)idx * 9] + 9);
-                tri_mat.push_back(s.tri_mat[idx]);
-                return (uint32_t)tri_mat.size() - 1;
+                tri_s.insert(tri_s.end(), &s.tri_v[(size_t)idx * 9], &s.tri_v[(size_t)idx * 9] + 9);
+                tri_s.insert(tri_s.end(), &s.tri_n[(size_t)idx * 9], &s.tri_n[(size_t)idx * 9] + 9);
+                uint64_t mbits = s.tri_mat[idx];
+                double md; std::memcpy(&md, &mbits, 8);
+                tri_s.push_back(md); tri_s.push_back(0.0);
+                return (uint32_t)(tri_s.size() / 20) - 1;
             }
             case ZR_PRIM_CUBE: {
                 cubes.insert(cubes.end(), &s.cubes[(size_t)idx * 12], &s.cubes[(size_t)idx * 12] + 6);
@@ -356,47 +359,129 @@ struct Flattener {
         double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
         return dx * dy + dy * dz + dz * dx;
     }
-    void quad_empty(uint32_t q, int slot) {
-        quads[q].lox[slot] = quads[q].loy[slot] = quads[q].loz[slot] = 0.f;
-        quads[q].hix[slot] = quads[q].hiy[slot] = quads[q].hiz[slot] = 0.f;
-        quads[q].child[slot] = 0; quads[q].meta[slot] = (1u << 16) | 0u;
-    }
-    void quad_child(uint32_t q, int slot, int32_t node_id, int depth) {
-        const zr::BuildNode& n = br.nodes[node_id];
-        quads[q].lox[slot] = f_down(n.box.lo[0]); quads[q].loy[slot] = f_down(n.box.lo[1]); quads[q].loz[slot] = f_down(n.box.lo[2]);
-        quads[q].hix[slot] = f_up(n.box.hi[0]); quads[q].hiy[slot] = f_up(n.box.hi[1]); quads[q].hiz[slot] = f_up(n.box.hi[2]);
-        if (n.count) { quads[q].child[slot] = leaf_first[node_id]; quads[q].meta[slot] = ((n.kind + 1u) << 16) | n.count; }
-        else { uint32_t c = emit_quad(node_id, depth + 1); quads[q].child[slot] = c; quads[q].meta[slot] = 0; }
-    }
-    uint32_t emit_quad(int32_t node_id, int depth) {
-        uint32_t q = (uint32_t)quads.size();
-        quads.push_back(zr::NodeQuad{});
-        quad_depth = std::max(quad_depth, depth);
-        int32_t kids[4]; int nk = 2;
-        kids[0] = br.nodes[node_id].left; kids[1] = br.nodes[node_id].right;
-        while (nk < 4) {
-            int best = -1; double ba = -1;
-            for (int k = 0; k < nk; k++) if (br.nodes[kids[k]].count == 0 && area(br.nodes[kids[k]].box) > ba) { ba = area(br.nodes[kids[k]].box); best = k; }
-            if (best < 0) break;
-            int32_t open = kids[best];
-            kids[best] = br.nodes[open].left; kids[nk++] = br.nodes[open].right;
+    // 8-bit planes of one axis: origin + q * scale, as a real number, must not exceed lo (lower plane) and must
+    // reach hi (upper plane).  origin is a float, scale a power of two not smaller than 2^-30 |origin|, so the sum is
+    // exact in long double and the comparison is the real one.
+    static long double plane(float origin, float scale, long q) { return (long double)origin + (long double)q * (long double)scale; }
+    static bool quant_axis(const double* lo, const double* hi, int n, float& origin, float& scale, uint8_t* qlo, uint8_t* qhi) {
+        double mn = lo[0], mx = hi[0];
+        for (int k = 1; k < n; k++) { mn = std::min(mn, lo[k]); mx = std::max(mx, hi[k]); }
+        if (!std::isfinite(mn) || !std::isfinite(mx) || std::fabs(mn) > 1e30 || std::fabs(mx) > 1e30) return false;
+        origin = f_down(mn);
+        const double ext = mx - (double)origin;
+        int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+        const int emin = origin != 0.0f ? std::max(-100, std::ilogb(origin) - 30) : -100;
+        if (e < emin) e = emin;
+        for (int tries = 0; tries < 64; tries++, e++) {
+            scale = std::ldexp(1.0f, e);
+            bool ok = true;
+            for (int k = 0; k < n && ok; k++) {
+                long ql = (long)std::floor((lo[k] - (double)origin) / (double)scale);
+                ql = std::min(255l, std::max(0l, ql));
+                while (ql > 0 && plane(origin, scale, ql) > (long double)lo[k]) ql--;
+                if (plane(origin, scale, ql) > (long double)lo[k]) ok = false;
+                long qh = (long)std::ceil((hi[k] - (double)origin) / (double)scale);
+                qh = std::min(255l, std::max(0l, qh));
+                while (qh < 255 && plane(origin, scale, qh) < (long double)hi[k]) qh++;
+                if (plane(origin, scale, qh) < (long double)hi[k]) ok = false;
+                qlo[k] = (uint8_t)ql; qhi[k] = (uint8_t)qh;
+            }
+            if (ok) return true;
         }
-        for (int k = 0; k < 4; k++) { if (k < nk) quad_child(q, k, kids[k], depth); else quad_empty(q, k); }
+        return false;
+    }
+    double open_ratio = 1.25;  // a child is not opened when that would put a box on the grid with more than this times its true area
+    zr::NodeF root{};
+    size_t n_kept_closed = 0;
+    // quantises the boxes of `kids` into nq; false when a box cannot be represented; *worst = largest area inflation
+    bool quantise(const int32_t* kids, int nk, zr::NodeQ& nq, double* worst) const {
+        uint8_t ql[3][4] = {}, qh[3][4] = {};
+        for (int k = 0; k < 6; k++) nq.q[k] = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            double lo[4], hi[4];
+            for (int k = 0; k < nk; k++) { lo[k] = br.nodes[kids[k]].box.lo[ax]; hi[k] = br.nodes[kids[k]].box.hi[ax]; }
+            if (!quant_axis(lo, hi, nk, nq.origin[ax], nq.scale[ax], ql[ax], qh[ax])) return false;
+            for (int k = 0; k < nk; k++) { nq.q[ax] |= (uint32_t)ql[ax][k] << (8 * k); nq.q[3 + ax] |= (uint32_t)qh[ax][k] << (8 * k); }
+        }
+        *worst = 1;
+        for (int k = 0; k < nk; k++) {
+            zr::BuildBox qb;
+            for (int ax = 0; ax < 3; ax++) {
+                qb.lo[ax] = (double)plane(nq.origin[ax], nq.scale[ax], ql[ax][k]);
+                qb.hi[ax] = (double)plane(nq.origin[ax], nq.scale[ax], qh[ax][k]);
+            }
+            const double at = area(br.nodes[kids[k]].box), aq = area(qb);
+            const double r = at > 0 ? aq / at : (aq > 0 ? 1e300 : 1.0);
+            if (!(r <= *worst)) *worst = r;
+        }
+        return true;
+    }
+    bool quant_ok = true;  // false: a box below the root is not finite (the caller falls back to variant 0)
+    // emits the 4-wide node made of build node `node_id`; the root goes to `root` (FP32), everything else to `quads`
+    uint32_t emit_quad(int32_t node_id, int depth) {
+        const bool is_root = depth == 0;
+        quad_depth = std::max(quad_depth, depth);
+        int32_t kids[4]; int nk = 0;
+        zr::NodeQ nq{};
+        for (int ax = 0; ax < 3; ax++) nq.scale[ax] = 1;
+        if (node_id >= 0 && br.nodes[node_id].count) kids[nk++] = node_id;  // a world that is a single leaf
+        else if (node_id >= 0) {
+            nk = 2;
+            kids[0] = br.nodes[node_id].left; kids[1] = br.nodes[node_id].right;
+            double worst = 1;
+            if (!is_root && !quantise(kids, nk, nq, &worst)) quant_ok = false;
+            while (nk < 4) {
+                // open the inner child with the largest area, unless the grid of the wider node would be too coarse
+                // for one of the boxes (then the child keeps its own node, whose grid fits its own children)
+                int best = -1; double ba = -1;
+                for (int k = 0; k < nk; k++) if (br.nodes[kids[k]].count == 0 && area(br.nodes[kids[k]].box) > ba) { ba = area(br.nodes[kids[k]].box); best = k; }
+                if (best < 0) break;
+                int32_t trial[4];
+                for (int k = 0; k < nk; k++) trial[k] = kids[k];
+                trial[best] = br.nodes[kids[best]].left; trial[nk] = br.nodes[kids[best]].right;
+                if (!is_root) {
+                    zr::NodeQ tq = nq; double w = 1;
+                    if (!quantise(trial, nk + 1, tq, &w)) { quant_ok = false; break; }
+                    if (w > open_ratio && w > worst) { n_kept_closed++; break; }
+                    nq = tq; worst = w;
+                }
+                for (int k = 0; k <= nk; k++) kids[k] = trial[k];
+                nk++;
+            }
+        }
+        uint32_t q = 0;
+        if (!is_root) { q = (uint32_t)quads.size(); quads.push_back(zr::NodeQ{}); }
+        uint32_t refs[4] = {ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY};
+        for (int k = 0; k < nk; k++) {
+            const zr::BuildNode& n = br.nodes[kids[k]];
+            if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[kids[k]];
+            else refs[k] = emit_quad(kids[k], depth + 1);
+        }
+        if (is_root) {
+            for (int k = 0; k < nk; k++) {
+                const zr::BuildBox& bb = br.nodes[kids[k]].box;
+                root.lox[k] = f_down(bb.lo[0]); root.loy[k] = f_down(bb.lo[1]); root.loz[k] = f_down(bb.lo[2]);
+                root.hix[k] = f_up(bb.hi[0]); root.hiy[k] = f_up(bb.hi[1]); root.hiz[k] = f_up(bb.hi[2]);
+            }
+            for (int k = 0; k < 4; k++) root.ref[k] = refs[k];
+            return 0;
+        }
+        for (int k = 0; k < 4; k++) nq.ref[k] = refs[k];
+        quads[q] = nq;
         return q;
     }
     void run() {
         leaf_first.assign(br.nodes.size(), 0);
         if (br.nodes.empty()) {
             pairs.push_back(zr::NodePair{}); empty_child(0, 0); empty_child(0, 1);
-            quads.push_back(zr::NodeQuad{}); for (int k = 0; k < 4; k++) quad_empty(0, k);
+            emit_quad(-1, 0);
             return;
         }
         if (br.nodes[0].count) {  // the whole world fits one leaf
             pairs.push_back(zr::NodePair{});
             set_child(0, 0, 0);
             empty_child(0, 1);
-            quads.push_back(zr::NodeQuad{});
-            quad_child(0, 0, 0, 0); for (int k = 1; k < 4; k++) quad_empty(0, k);
+            emit_quad(0, 0);
             return;
         }
         emit_pair(0);
@@ -430,9 +515,10 @@ zr_ctx* zr_create(int device_ordinal) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
     }
-    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) {
-        fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
-    }
+    for (int k = 1; k < ST_MAX_POOLS; k++)
+        if ((e = hipStreamCreateWithFlags(&c->sub[k], hipStreamNonBlocking)) != hipSuccess) {
+            fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
+        }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
     c->variant = (int)env_double("ZR_KERNEL", 2);
     c->log_kind = (int)env_double("ZR_TIMELOG_KIND", 1);
@@ -442,12 +528,11 @@ zr_ctx* zr_create(int device_ordinal) {
         if (over > 0) c->st_blocks = over;
         c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
         c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
-        // auto: on for sharded frames (a rank's 1/8 of cfg3: 71.8 -> 67.1 ms, the halves fill each other's ramp and
-        // tail), off for whole frames (+1 % only: the pipeline is HBM-bound and the co-running launches just stretch)
-        c->st_overlap = (int)env_double("ZR_STREAM_OVERLAP", -1);
-        if (c->d_ctl.alloc(3 * zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(2 * zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
+        c->st_pools = (int)env_double("ZR_STREAM_POOLS", -1);
+        if (env_double("ZR_STREAM_OVERLAP", -1) == 0) c->st_pools = 1;
+        if (c->d_ctl.alloc((ST_MAX_POOLS + 1) * zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(ST_MAX_POOLS * zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
             hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc((void**)&c->h_active, 2 * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
+            hipHostMalloc((void**)&c->h_active, ST_MAX_POOLS * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
     if (c->variant == 1) {
         c->wf_blocks = zr::wavefront_max_blocks();
@@ -470,7 +555,7 @@ void zr_destroy(zr_ctx* c) {
     if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->st_event) (void)hipEventDestroy(c->st_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int k = 1; k < ST_MAX_POOLS; k++) if (c->sub[k]) (void)hipStreamDestroy(c->sub[k]);
     delete c;
 }
 
@@ -592,17 +677,18 @@ int zr_scene_commit(zr_scene* s) {
     if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
 
     Flattener fl{*s, objs, br};
+    fl.open_ratio = env_double("ZR_BVH_OPEN_RATIO", 1.25);
     fl.run();
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
-    s->quad_ok = max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_mat.size() < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
+    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
+    s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
                  fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24);
     if ((rc = s->d_spheres.upload(fl.spheres))) return rc;
     if ((rc = s->d_sphere_mat.upload(fl.sphere_mat))) return rc;
     if ((rc = s->d_tri_v.upload(fl.tri_v))) return rc;
-    if ((rc = s->d_tri_n.upload(fl.tri_n))) return rc;
-    if ((rc = s->d_tri_mat.upload(fl.tri_mat))) return rc;
+    if ((rc = s->d_tri_s.upload(fl.tri_s))) return rc;
     if ((rc = s->d_cubes.upload(fl.cubes))) return rc;
     if ((rc = s->d_cube_mat.upload(fl.cube_mat))) return rc;
     if ((rc = s->d_media.upload(fl.media))) return rc;
@@ -632,16 +718,16 @@ int zr_scene_commit(zr_scene* s) {
     zr::DScene& d = s->ds;
     d.nodes = s->d_nodes.p; d.quads = s->d_quads.p;
     d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
-    d.tri_v = s->d_tri_v.p; d.tri_n = s->d_tri_n.p; d.tri_mat = s->d_tri_mat.p;
+    d.tri_v = s->d_tri_v.p; d.tri_s = s->d_tri_s.p;
     d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
     d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.ops = s->d_ops.p;
     d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
     d.n_mats = (uint32_t)s->materials.size();
-    d.root_meta = 0;
+    d.root = fl.root;
     s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
     s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
-    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQuad) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_n.size() + fl.cubes.size()) * 8 +
-                  (fl.sphere_mat.size() + fl.tri_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
+    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size()) * 8 +
+                  (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
     s->committed = true;
     return ZR_OK;
 }
@@ -801,16 +887,20 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
         if (units < P) P = (uint32_t)((units + 63) / 64 * 64);
     }
     int rc;
-    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536))) return rc;
+    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS))) return rc;
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
     if (keep_going) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame reduces what exists
     HostTimer timer(c);
     int rounds = 0;
+    hipStream_t streams[ST_MAX_POOLS];
+    streams[0] = stream;
+    for (int k = 1; k < ST_MAX_POOLS; k++) streams[k] = c->sub[k];
+    const bool sharded = (size_t)plan.tiles.size() < (size_t)plan.tiles_x * plan.tiles_y;
+    const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
-                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, stream, c->stream2, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->generic_leaves,
-                                     c->st_overlap < 0 ? (size_t)plan.tiles.size() < (size_t)plan.tiles_x * plan.tiles_y : c->st_overlap != 0);
+                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
+                                     keep_going, &rounds, s->generic_leaves);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));
@@ -1015,7 +1105,7 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
     unsigned long long h[16];
     HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[15] != 0) return fail(ZR_E_DEVICE, "render kernel hit its iteration cap on %llu task(s): results are incomplete", h[15]);
-    if (c->last_counted) {
+    if (c->last_counted || env_double("ZR_RAW_COUNTERS", 0) != 0) {
         out->primary_samples = h[0]; out->segments = h[1]; out->nodes_tested = h[2]; out->spheres_tested = h[3];
         out->triangles_tested = h[4]; out->cubes_tested = h[5]; out->media_tested = h[6]; out->hits = h[7]; out->rng_draws = h[8];
         out->node_execs = h[9]; out->node_lanes = h[10]; out->leaf_execs = h[11]; out->leaf_lanes = h[12]; out->shade_execs = h[13]; out->shade_lanes = h[14];

@@ -35,14 +35,15 @@ struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 exten
     virtual void end(hipStream_t, int kind) = 0;
     virtual ~StreamTimer() = default;
 };
+#define ST_MAX_POOLS 8   /* sub-pools of the slot pool, one HIP stream each */
 size_t stream_overflow_bytes(int blocks);
 size_t stream_ctl_words();
 int stream_extend_blocks();
 size_t stream_pool_bytes(uint32_t P);
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
-                         double* out, unsigned long long* gctr, bool count, hipStream_t stream, hipStream_t stream2, hipEvent_t ev, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, bool overlap);
+                         double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic);
 hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const WorkDesc& wd, int aux, double zmax, const double* uvw9,
                       double* out_albedo, double* out_normal, double* out_zdepth, hipStream_t stream);
 hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,

@@ -102,14 +102,23 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 }
 
 // ---- EXTEND: closest hit for every active slot ------------------------------------------------------------
-// Walks the 4-wide tree (NodeQuad, 128 B = one L2 line per step).  Box tests are FP32 and CONSERVATIVE: with
-// o = o_hi + o_lo (+ <= 2^-48 |o|), t = ((b - o_hi) - o_lo) * id carries a relative error below 2^-21 (two
-// subtractions, the product, the rounding of 1/d to float), so the entry distance is lowered and the exit distance
-// raised by |t| * 2^-20 plus an absolute slack c_ray for the dropped origin bits.  A superset of box hits cannot change
-// the closest primitive; every primitive test stays FP64.  A NaN slab (0 * inf) is ignored by fminf/fmaxf, which
-// keeps the box (conservative).
+// Walks the 4-wide tree (zr_device_types.h: FP32 root in the kernel arguments, 64-byte nodes with boxes on an 8-bit
+// grid below it).  The kernel is bound by VALU issue and node fetches together (rocprofv3: SQ_INSTS_VALU x 4 clocks /
+// 1024 SIMDs ~ its duration; 128-byte FP32 nodes with fewer operations per visit were 15 % slower), so the slab test
+// is arranged for the fewest operations, and it is CONSERVATIVE: a superset of box hits cannot change the closest
+// primitive, and every primitive test stays FP64.
+//   per ray:   id = 1 / (float)d (float, taken as exact: it perturbs t by a relative 2^-23),  c = (float)(-o * id)
+//   per plane: t = fmaf(P, id, c)                          (root: P is an FP32 plane)
+//              t = fmaf(q, a, b), a = scale * id (exact, scale is a power of two), b = fmaf(origin, id, c)
+//   error:     |t - (P - o) id| <= 2^-24 (|t| + |b| + |c|), and |b| <= |t| + 255 |a|
+// The absolute part of that bound is folded, per axis, into the constants: the plane a ray meets first on an axis
+// (the lower one when id > 0) uses c_n = c - 2^-22 |c|, the other one c_f = c + 2^-22 |c| (and b_n, b_f move by a
+// further 2^-15 |a|); a slack shared by the three axes would let an axis with a tiny d inflate the other two.  The
+// relative part lowers the entry distance and raises the exit distance by |t| 2^-20.  An axis whose 1/d or o/d
+// leaves the float range gets id = 0, c = NaN: its planes evaluate to NaN, which fminf/fmaxf ignore, i.e. the slab
+// is dropped (conservative).
 enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2 };
-#define X_LEAF_BIT 0x80000000u
+#define X_LEAF_BIT ZR_REF_LEAF
 
 __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32_t& rb) {
     const bool sw = tb < ta;
@@ -134,7 +143,8 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     int st = X_IDLE;
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
-    float ohx = 0, ohy = 0, ohz = 0, olx = 0, oly = 0, olz = 0, idx_ = 0, idy_ = 0, idz_ = 0, c_ray = 0;
+    float idx_ = 0, idy_ = 0, idz_ = 0;
+    float clx = 0, cly = 0, clz = 0, chx = 0, chy = 0, chz = 0;  // per axis: c for the LOWER plane and for the UPPER plane (slack folded in)
     double tbest = INF;
     float tbest_f = INFf;
     uint32_t kbest = NONE, ibest = 0;
@@ -174,8 +184,40 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         if (e_.tn <= tbest_f) { cur = e_.node; pend_i = 0; st = (e_.node & X_LEAF_BIT) ? X_LEAF : X_NODE; break; } \
     }
 
+// one child from the parametric distances of its six planes (absolute slack already inside): entry distance or +inf
+#define ZR_SLAB(X0, X1, Y0, Y1, Z0, Z1, RF_IN, TN, RF)                                                      \
+    {                                                                                                       \
+        const float x0 = (X0), x1 = (X1), y0 = (Y0), y1 = (Y1), z0 = (Z0), z1 = (Z1);                       \
+        float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.000999f));            \
+        float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest_f));              \
+        n_ = fmaf(fabsf(n_), -9.5367432e-7f, n_);                                                           \
+        f_ = fmaf(fabsf(f_), 9.5367432e-7f, f_);                                                            \
+        const bool empty_ = (RF_IN) == ZR_REF_EMPTY;                                                        \
+        const bool hit_ = (n_ <= f_) && !empty_;                                                            \
+        if (COUNT && !empty_) c_nodes++;                                                                    \
+        TN = hit_ ? n_ : INFf;                                                                              \
+        RF = (RF_IN);                                                                                       \
+    }
+#define ZR_FBOX(N, C, TN, RF)                                                                               \
+    ZR_SLAB(fmaf((N).lox[C], idx_, clx), fmaf((N).hix[C], idx_, chx), fmaf((N).loy[C], idy_, cly), fmaf((N).hiy[C], idy_, chy), \
+            fmaf((N).loz[C], idz_, clz), fmaf((N).hiz[C], idz_, chz), (N).ref[C], TN, RF)
+// the four children by entry distance (5-comparator network): push far -> near, continue with the nearest
+#define ZR_DESCEND()                                                                                        \
+    {                                                                                                       \
+        cswap(tn0, r0, tn1, r1); cswap(tn2, r2, tn3, r3); cswap(tn0, r0, tn2, r2); cswap(tn1, r1, tn3, r3); cswap(tn1, r1, tn2, r2); \
+        if (tn3 < INFf) ZR_PUSH(r3, tn3)                                                                    \
+        if (tn2 < INFf) ZR_PUSH(r2, tn2)                                                                    \
+        if (tn1 < INFf) ZR_PUSH(r1, tn1)                                                                    \
+        if (tn0 < INFf) { cur = r0; pend_i = 0; st = (r0 & X_LEAF_BIT) ? X_LEAF : X_NODE; }                 \
+        else { ZR_POP_NEXT() }                                                                              \
+    }
+
     const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
     unsigned long long iter = 0;
+#ifdef ZR_WAVE_PROFILE
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long p_exec[3] = {0, 0, 0}, p_lanes[3] = {0, 0, 0};
+#endif
     for (; iter < iter_cap; iter++) {
         const uint32_t lkind = (cur >> 28) & 7u;
         const int n1 = __popcll(__ballot(st == X_NODE));
@@ -191,6 +233,9 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays
             const unsigned long long idle = __ballot(st == X_IDLE);
             uint32_t n = (uint32_t)__popcll(idle);
+#ifdef ZR_WAVE_PROFILE
+            p_exec[2]++; p_lanes[2] += n;
+#endif
             while (chunk_next >= chunk_end && work_left) {
                 // reserve the next chunk of this wave's shard; an exhausted shard sends the wave to the next one
                 uint32_t nb = 0;
@@ -218,60 +263,66 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
                         slot = my;
                         ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
                         if (GENERIC) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
-                        ohx = (float)ray.o.x; ohy = (float)ray.o.y; ohz = (float)ray.o.z;
-                        olx = (float)(ray.o.x - (double)ohx); oly = (float)(ray.o.y - (double)ohy); olz = (float)(ray.o.z - (double)ohz);
-                        idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
-                        const float mo = fmaxf(fmaxf(fabsf(ohx), fabsf(ohy)), fabsf(ohz));
-                        const float mi = fmaxf(fmaxf(fabsf(idx_), fabsf(idy_)), fabsf(idz_));
-                        c_ray = mo * mi * 2.8421709e-14f;  // 2^-45: the origin bits beyond o_hi + o_lo, with slack
-                        if (!(c_ray < INFf)) c_ray = 0.0f;  // a zero direction component: that slab is +-inf / NaN anyway
+                        {
+                            const float NANf = __builtin_nanf("");
+                            idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
+                            float ocx = (float)(-ray.o.x * (double)idx_), ocy = (float)(-ray.o.y * (double)idy_), ocz = (float)(-ray.o.z * (double)idz_);
+                            // 2^100 / 2^120: far inside the float range, so that no product with a plane or a scale overflows
+                            if (!(fabsf(idx_) < 1.2676506e30f) || !(fabsf(ocx) < 1.3292280e36f)) { idx_ = 0.0f; ocx = NANf; }
+                            if (!(fabsf(idy_) < 1.2676506e30f) || !(fabsf(ocy) < 1.3292280e36f)) { idy_ = 0.0f; ocy = NANf; }
+                            if (!(fabsf(idz_) < 1.2676506e30f) || !(fabsf(ocz) < 1.3292280e36f)) { idz_ = 0.0f; ocz = NANf; }
+                            // the lower plane is the entry plane when id > 0: it gets the smaller constant
+                            const float sx = copysignf(fabsf(ocx) * 2.3841858e-7f, idx_), sy = copysignf(fabsf(ocy) * 2.3841858e-7f, idy_), sz = copysignf(fabsf(ocz) * 2.3841858e-7f, idz_);
+                            clx = ocx - sx; chx = ocx + sx; cly = ocy - sy; chy = ocy + sy; clz = ocz - sz; chz = ocz + sz;
+                        }
                         tbest = INF; tbest_f = INFf; kbest = NONE; cur = 0; sp = 0; pend_i = 0;
-                        st = X_NODE;
                         if (COUNT) c_seg++;
+                        // the root's FP32 boxes come with the kernel arguments: no memory access for the first step, and a
+                        // ray that misses the whole world is finished right here
+                        float tn0, tn1, tn2, tn3;
+                        uint32_t r0, r1, r2, r3;
+                        ZR_FBOX(sc.root, 0, tn0, r0)
+                        ZR_FBOX(sc.root, 1, tn1, r1)
+                        ZR_FBOX(sc.root, 2, tn2, r2)
+                        ZR_FBOX(sc.root, 3, tn3, r3)
+                        ZR_DESCEND()
                     }
                 }
             }
         } else if (n1 >= n2) {
             // ================= NODE: one 4-wide node per lane =================
             if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
+#ifdef ZR_WAVE_PROFILE
+            p_exec[0]++; p_lanes[0] += n1;
+#endif
             if (st == X_NODE) {
-                const float4* nq = reinterpret_cast<const float4*>(sc.quads + cur);
-                const float4 lx = nq[0], ly = nq[1], lz = nq[2], hx = nq[3], hy = nq[4], hz = nq[5];
-                const uint4 ch = reinterpret_cast<const uint4*>(nq)[6];
-                const uint4 me = reinterpret_cast<const uint4*>(nq)[7];
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
-#define ZR_BOX(LX, LY, LZ, HX, HY, HZ, CH, ME, TN, RF)                                                        \
-    {                                                                                                       \
-        const float x0 = (((LX) - ohx) - olx) * idx_, x1 = (((HX) - ohx) - olx) * idx_;                     \
-        const float y0 = (((LY) - ohy) - oly) * idy_, y1 = (((HY) - ohy) - oly) * idy_;                     \
-        const float z0 = (((LZ) - ohz) - olz) * idz_, z1 = (((HZ) - ohz) - olz) * idz_;                     \
-        float n_ = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.000999f));            \
-        float f_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tbest_f));              \
-        n_ = n_ - (fabsf(n_) * 9.5367432e-7f + c_ray);                                                      \
-        f_ = f_ + (fabsf(f_) * 9.5367432e-7f + c_ray);                                                      \
-        const bool empty_ = (ME) != 0u && ((ME) & 0xFFFFu) == 0u;                                           \
-        const bool hit_ = (n_ <= f_) && !empty_;                                                            \
-        if (COUNT && !empty_) c_nodes++;                                                                    \
-        TN = hit_ ? n_ : INFf;                                                                              \
-        RF = (ME) == 0u ? (CH) : (X_LEAF_BIT | ((((ME) >> 16) - 1u) << 28) | ((((ME) & 0xFFFFu) - 1u) << 24) | (CH)); \
-    }
-                ZR_BOX(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, ch.x, me.x, tn0, r0)
-                ZR_BOX(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, ch.y, me.y, tn1, r1)
-                ZR_BOX(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, ch.z, me.z, tn2, r2)
-                ZR_BOX(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, ch.w, me.w, tn3, r3)
-#undef ZR_BOX
-                // sort by entry distance (5-comparator network), push far -> near, continue with the nearest
-                cswap(tn0, r0, tn1, r1); cswap(tn2, r2, tn3, r3); cswap(tn0, r0, tn2, r2); cswap(tn1, r1, tn3, r3); cswap(tn1, r1, tn2, r2);
-                if (tn3 < INFf) ZR_PUSH(r3, tn3)
-                if (tn2 < INFf) ZR_PUSH(r2, tn2)
-                if (tn1 < INFf) ZR_PUSH(r1, tn1)
-                if (tn0 < INFf) { cur = r0; pend_i = 0; st = (r0 & X_LEAF_BIT) ? X_LEAF : X_NODE; }
-                else { ZR_POP_NEXT() }
+                const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
+                const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
+                // t = fmaf(q, a, b): a = scale * id, b = the node origin's parametric distance (the lower planes' b moved
+                // by -2^-15 a, the upper planes' by +2^-15 a: towards "earlier" resp. "later" whatever the sign of id)
+                const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
+                const float blx = fmaf(ax_, -3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, clx)), bhx = fmaf(ax_, 3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, chx));
+                const float bly = fmaf(ay_, -3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, cly)), bhy = fmaf(ay_, 3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, chy));
+                const float blz = fmaf(az_, -3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, clz)), bhz = fmaf(az_, 3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, chz));
+#define ZR_QBOX(C, RF_IN, TN, RF)                                                                                          \
+    ZR_SLAB(fmaf((float)((w1.z >> (8 * C)) & 0xFFu), ax_, blx), fmaf((float)((w2.y >> (8 * C)) & 0xFFu), ax_, bhx),         \
+            fmaf((float)((w1.w >> (8 * C)) & 0xFFu), ay_, bly), fmaf((float)((w2.z >> (8 * C)) & 0xFFu), ay_, bhy),         \
+            fmaf((float)((w2.x >> (8 * C)) & 0xFFu), az_, blz), fmaf((float)((w2.w >> (8 * C)) & 0xFFu), az_, bhz), RF_IN, TN, RF)
+                ZR_QBOX(0, ref.x, tn0, r0)
+                ZR_QBOX(1, ref.y, tn1, r1)
+                ZR_QBOX(2, ref.z, tn2, r2)
+                ZR_QBOX(3, ref.w, tn3, r3)
+#undef ZR_QBOX
+                ZR_DESCEND()
             }
         } else {
             // ================= LEAF: one primitive per lane, the kind with most waiting lanes =================
             if (COUNT) { s_exec[1]++; s_lanes[1] += n2; }
+#ifdef ZR_WAVE_PROFILE
+            p_exec[1]++; p_lanes[1] += n2;
+#endif
             const bool is_leaf = st == X_LEAF;
             const bool do_tri = n2t == n2;
             const bool do_sph = !do_tri && n2s == n2;
@@ -308,6 +359,12 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         }
     }
     if (iter >= iter_cap && lane == 0) atomicAdd(&B.ctl[2], 1u);
+#ifdef ZR_WAVE_PROFILE
+    if (!COUNT && lane == 0) {  // development build: wave lifetime (10 ns ticks) and phase statistics into the raw counter words
+        atomicAdd(&gctr[13], wall_clock64() - t_begin); atomicAdd(&gctr[14], 1ull);
+        for (int k = 0; k < 3; k++) { atomicAdd(&gctr[1 + 2 * k], p_exec[k]); atomicAdd(&gctr[2 + 2 * k], p_lanes[k]); }
+    }
+#endif
     if (COUNT) {
         atomicAdd(&gctr[1], (unsigned long long)c_seg);
         atomicAdd(&gctr[2], (unsigned long long)c_nodes);
@@ -520,77 +577,85 @@ static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, 
     else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
 }
 
-// The slot pool is split into two halves that run half a round apart on two HIP streams: while one half is in
-// EXTEND (dependent BVH fetches, ALU) the other is in SHADE (HBM-bandwidth bound state streaming), so the two stages
-// overlap on the chip instead of alternating.  `stream` is the caller's stream (half A), `stream2` an internal one.
+// The slot pool can be split into K sub-pools that run a fraction of a round apart on K HIP streams, so that one
+// pool's EXTEND overlaps another's SHADE.  Measured on cfg3: K = 2 gains 1-3 % on a whole frame and 6 % on a rank's
+// 1/8 shard, K >= 3 loses (the stages are throughput-bound, co-running launches only stretch each other).
+// streams[0] is the caller's stream, the others are internal.
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
-                         double* out, unsigned long long* gctr, bool count, hipStream_t stream, hipStream_t stream2, hipEvent_t ev, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, bool overlap) {
+                         double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
-    // two halves (B empty when the pool is small or overlap is off)
-    uint32_t PA = P, PB = 0;
-    if (overlap && P >= 2u * 64u * 1024u) { PA = (P / 2 + 63) / 64 * 64; PB = P - PA; }
-    StreamBuf A = make_buf(pool, PA, spp, n_units, n_pix, d_pixels, d_samples, d_ctl, d_ctl + 2 * W, 0, P);
-    StreamBuf Bb = make_buf((unsigned char*)pool + stream_pool_bytes(PA), PB, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + W, d_ctl + 2 * W, PA, P);
-    void* ovA = d_overflow;
-    void* ovB = (unsigned char*)d_overflow + stream_overflow_bytes(extend_blocks);
+    int K = n_pools < 1 ? 1 : (n_pools > ST_MAX_POOLS ? ST_MAX_POOLS : n_pools);
+    while (K > 1 && P / K < 64u * 1024u) K--;
+    StreamBuf Q[ST_MAX_POOLS];
+    void* ov[ST_MAX_POOLS];
+    unsigned int* uctl = d_ctl + (size_t)ST_MAX_POOLS * W;
+    {
+        uint32_t first = 0;
+        unsigned char* base = (unsigned char*)pool;
+        for (int k = 0; k < K; k++) {
+            uint32_t Pk = k == K - 1 ? P - first : (P / K + 63) / 64 * 64;
+            Q[k] = make_buf(base, Pk, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + (size_t)k * W, uctl, first, P);
+            ov[k] = (unsigned char*)d_overflow + (size_t)k * stream_overflow_bytes(extend_blocks);
+            base += stream_pool_bytes(Pk);
+            first += Pk;
+        }
+    }
     hipError_t e;
-    if ((e = hipMemsetAsync(d_ctl, 0, 3 * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
-    auto init = [&](const StreamBuf& Q, hipStream_t st) {
+    hipStream_t stream = streams[0];
+    if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    auto init = [&](const StreamBuf& B, hipStream_t st) {
         if (timer) timer->begin(st, 0);
-        if (count) hipLaunchKernelGGL(stream_init<true>, dim3((Q.P + 255) / 256), dim3(256), 0, st, Q, cam, seed, gctr);
-        else hipLaunchKernelGGL(stream_init<false>, dim3((Q.P + 255) / 256), dim3(256), 0, st, Q, cam, seed, gctr);
+        if (count) hipLaunchKernelGGL(stream_init<true>, dim3((B.P + 255) / 256), dim3(256), 0, st, B, cam, seed, gctr);
+        else hipLaunchKernelGGL(stream_init<false>, dim3((B.P + 255) / 256), dim3(256), 0, st, B, cam, seed, gctr);
         if (timer) timer->end(st, 0);
     };
-    auto extend = [&](const StreamBuf& Q, void* ov, hipStream_t st) {
-        const int eb = (int)((Q.P + 63) / 64 < (uint32_t)extend_blocks ? (Q.P + 63) / 64 : (uint32_t)extend_blocks);
+    auto extend = [&](const StreamBuf& B, void* o, hipStream_t st) {
+        const int eb = (int)((B.P + 63) / 64 < (uint32_t)extend_blocks ? (B.P + 63) / 64 : (uint32_t)extend_blocks);
         if (timer) timer->begin(st, 1);
-        if (count) launch_extend<true>(sc, Q, ov, eb, gctr, generic, st); else launch_extend<false>(sc, Q, ov, eb, gctr, generic, st);
+        if (count) launch_extend<true>(sc, B, o, eb, gctr, generic, st); else launch_extend<false>(sc, B, o, eb, gctr, generic, st);
         if (timer) timer->end(st, 1);
     };
-    auto shade = [&](const StreamBuf& Q, hipStream_t st) {
+    auto shade = [&](const StreamBuf& B, hipStream_t st) {
         if (timer) timer->begin(st, 2);
-        if (count) hipLaunchKernelGGL(stream_shade<true>, dim3((Q.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, Q, gctr);
-        else hipLaunchKernelGGL(stream_shade<false>, dim3((Q.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, Q, gctr);
+        if (count) hipLaunchKernelGGL(stream_shade<true>, dim3((B.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, B, gctr);
+        else hipLaunchKernelGGL(stream_shade<false>, dim3((B.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, B, gctr);
         if (timer) timer->end(st, 2);
     };
-    init(A, stream);
-    if (PB) {
-        // half B starts after the buffers are initialised and half a round late: it waits for A's first EXTEND
-        extend(A, ovA, stream);
-        if ((e = hipEventRecord(ev, stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(stream2, ev, 0)) != hipSuccess) return e;
-        init(Bb, stream2);
-        shade(A, stream);
+    // start-up: pool k is initialised after the control words are cleared and starts once pool k-1 has a round in flight
+    init(Q[0], stream);
+    for (int k = 1; k < K; k++) {
+        extend(Q[k - 1], ov[k - 1], streams[k - 1]);
+        if ((e = hipEventRecord(ev, streams[k - 1])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(streams[k], ev, 0)) != hipSuccess) return e;
+        init(Q[k], streams[k]);
+        shade(Q[k - 1], streams[k - 1]);
     }
-    int rounds = PB ? 1 : 0;
+    int rounds = K > 1 ? 1 : 0;
     int check_every = 8;
     bool cancelled = false;
     for (;;) {
-        for (int k = 0; k < check_every; k++) {
-            if (PB) { extend(Bb, ovB, stream2); shade(Bb, stream2); }
-            extend(A, ovA, stream); shade(A, stream);
+        for (int r = 0; r < check_every; r++) {
+            for (int k = K - 1; k >= 0; k--) { extend(Q[k], ov[k], streams[k]); shade(Q[k], streams[k]); }
             rounds++;
         }
-        if ((e = hipMemcpyAsync(h_active, d_ctl, 2 * W * sizeof(unsigned int), hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
-        if (PB) {
-            // the copy on `stream` must see half B's counters: join stream2 into stream first
-            if ((e = hipStreamSynchronize(stream2)) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(h_active + W, d_ctl + W, W * sizeof(unsigned int), hipMemcpyDeviceToHost, stream2)) != hipSuccess) break;
-            if ((e = hipStreamSynchronize(stream2)) != hipSuccess) break;
-        }
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
+        for (int k = 0; k < K && e == hipSuccess; k++)
+            e = hipMemcpyAsync(h_active + (size_t)k * W, d_ctl + (size_t)k * W, W * sizeof(unsigned int), hipMemcpyDeviceToHost, streams[k]);
+        for (int k = K - 1; k >= 0 && e == hipSuccess; k--) e = hipStreamSynchronize(streams[k]);
+        if (e != hipSuccess) break;
         unsigned long long active = 0;
-        for (int sh = 0; sh < ST_SHARDS; sh++) active += (unsigned long long)h_active[16 + 32 * sh + 16] + (PB ? h_active[W + 16 + 32 * sh + 16] : 0u);
+        for (int k = 0; k < K; k++)
+            for (int sh = 0; sh < ST_SHARDS; sh++) active += h_active[(size_t)k * W + 16 + 32 * sh + 16];
         if (active == 0) break;
         check_every = active > P / 2 ? 8 : (active > P / 16 ? 4 : 2);
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }
     if (e != hipSuccess) return e;
-    if (h_active[2] != 0 || (PB && h_active[W + 2] != 0)) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
+    for (int k = 0; k < K; k++) if (h_active[(size_t)k * W + 2] != 0) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
+    const StreamBuf& A = Q[0];
     if (timer) timer->begin(stream, 3);
     hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
