@@ -41,7 +41,9 @@ namespace zr {
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
+#ifndef ST_LDS_STACK
 #define ST_LDS_STACK 12
+#endif
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
 enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18 };  // meta.y: bounce | b_inner << 8 | flags (F_L0: SF_SUM holds the primary hit's emission)
@@ -389,6 +391,9 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     __shared__ unsigned char perm[256];
     __shared__ unsigned int wave_hits[4];
     uint32_t slot;
+#ifdef ZR_SHADE_NO_PARTITION
+    slot = slot0;
+#else
     {
         bool is_hit = false;
         if (slot0 < B.P) {
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
         __syncthreads();
         slot = blockIdx.x * 256 + perm[threadIdx.x];
     }
+#endif
     bool active_after = false, want_unit = false;
     uint32_t c_samp = 0; unsigned long long c_draws = 0;
     if (slot < B.P) {
