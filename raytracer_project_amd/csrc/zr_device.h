@@ -352,14 +352,25 @@ __device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx,
     }
 }
 
+// Slab constants of one axis for t = fma(P, id, -o_id).  With a zero direction component id = +-inf, and P * inf - o * inf
+// is -inf for one plane and NaN for the other whenever o lies between them: fmin/fmax would then keep the -inf and
+// cull a box the ray runs through.  Such an axis (and one whose o / d overflows) gets id = 0, o_id = NaN instead:
+// both planes evaluate to NaN, fmin/fmax ignore them and the slab is dropped — conservative.  (aabb.hpp:44-66 relies on
+// IEEE inf arithmetic of (P - o) * inf, which has no such mixed case.)
+__device__ __forceinline__ void slab_constants(double d, double o, double& id, double& o_id) {
+    id = 1.0 / d;
+    o_id = o * id;
+    if (!(fabs(id) < 1e300) || !(fabs(o_id) < 1e300)) { id = 0.0; o_id = __builtin_nan(""); }
+}
+
 // ---- closest hit: BVH walk (replaces bvh_node::hit, bvh.hpp:46-54,112-118 + aabb::hit, aabb.hpp:44-66) ----
 // `stack` is this lane's column of the workgroup's LDS traversal stack: entry i lives at stack[i * stride].
 // Returns the leaf object and distance of the closest hit in (tmin, +inf).
 template <bool COUNT>
 __device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, const Rng& g, uint32_t* stack, int stride,
                                    double& t_out, uint32_t& kind_out, uint32_t& idx_out, Counters& ctr) {
-    const double idx_ = 1.0 / r.d.x, idy_ = 1.0 / r.d.y, idz_ = 1.0 / r.d.z;
-    const double ox_ = r.o.x * idx_, oy_ = r.o.y * idy_, oz_ = r.o.z * idz_;
+    double idx_, idy_, idz_, ox_, oy_, oz_;
+    slab_constants(r.d.x, r.o.x, idx_, ox_); slab_constants(r.d.y, r.o.y, idy_, oy_); slab_constants(r.d.z, r.o.z, idz_, oz_);
     double tbest = __builtin_huge_val();
     uint32_t kbest = 0xFFFFFFFFu, ibest = 0;
     int sp = 0;
@@ -388,7 +399,7 @@ __device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, 
             tn[1] = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), tmin));
             tf[1] = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
         }
-        // a NaN slab (0 * inf) makes fmin/fmax ignore that slab: conservative
+        // an axis the ray does not move along evaluates to NaN on both planes (slab_constants): fmin/fmax ignore it
         bool h0 = tn[0] <= tf[0], h1 = tn[1] <= tf[1];
         const uint32_t c[2] = {q3.x, q3.y};
         const uint32_t m[2] = {q3.z, q3.w};

@@ -1135,8 +1135,27 @@ int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double
     int rc;
     if ((rc = d_rays.upload(r))) return rc;
     if ((rc = d_hits.alloc(n))) return rc;
-    HIP_OK(zr::launch_trace(s->ds, d_rays.p, n, tmin, tmax, seed, pixel, bounce, d_hits.p, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    // Two engines answer the same question: the pair-BVH walk of variants 0/1 and — for the render interval
+    // [0.001, inf) — the EXTEND kernel of the streaming pipeline.  ZR_TRACE_ENGINE=pairs|extend picks one (tests run
+    // both); by default the engine of the active render variant is used.
+    const char* eng = std::getenv("ZR_TRACE_ENGINE");
+    const bool can_extend = c->variant == 2 && s->quad_ok && tmin == 0.001 && tmax == HUGE_VAL && n < (1u << 30);
+    if (eng && std::strcmp(eng, "extend") == 0 && !can_extend)
+        return fail(ZR_E_INVALID, "ZR_TRACE_ENGINE=extend needs ZR_KERNEL=2, tmin = 0.001, tmax = inf and a scene within the 4-wide tree's limits");
+    if (can_extend && !(eng && std::strcmp(eng, "pairs") == 0)) {
+        DevBuf<unsigned char> pool;
+        if ((rc = pool.alloc(zr::stream_pool_bytes((uint32_t)n) + 65536))) return rc;
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_OK(zr::stream_trace(s->ds, d_rays.p, (uint32_t)n, seed, pixel, bounce, d_hits.p, pool.p, c->d_ctl.p, c->d_st_overflow.p, c->st_blocks,
+                                c->d_ctr.p, s->generic_leaves, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        unsigned int capped = 0;
+        HIP_OK(hipMemcpy(&capped, c->d_ctl.p + 2, sizeof capped, hipMemcpyDeviceToHost));
+        if (capped) return fail(ZR_E_DEVICE, "EXTEND hit its iteration cap on %u wave(s)", capped);
+    } else {
+        HIP_OK(zr::launch_trace(s->ds, d_rays.p, n, tmin, tmax, seed, pixel, bounce, d_hits.p, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
     if (n) HIP_OK(hipMemcpy(out, d_hits.p, n * sizeof(zr_hit), hipMemcpyDeviceToHost));
     return ZR_OK;
 }

@@ -550,6 +550,42 @@ __global__ __launch_bounds__(256) void stream_reduce(StreamBuf B, DCamera cam, d
     }
 }
 
+// ---- known-answer path: a batch of caller-supplied rays through EXTEND (zr_trace) ------------------------------------
+// slot k = ray k, RNG key as in trace_rays (zr_kernels.hip) so that a medium's draw is the same on both engines
+__global__ __launch_bounds__(256) void stream_load_rays(StreamBuf B, const double* __restrict__ rays, uint32_t n, uint64_t seed, uint64_t pixel,
+                                                         uint32_t bounce) {
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= B.P) return;
+    uint2 ma; ma.x = 0; ma.y = 0;
+    if (slot < n) {
+        B.st3(SF_RAY, slot, ld3(rays + (size_t)slot * 6)); B.st3(SF_RAY + 3, slot, ld3(rays + (size_t)slot * 6 + 3));
+        B.st(SF_KEY, slot, __longlong_as_double((long long)zr_stream_key(seed, pixel, (uint64_t)slot)));
+        ma.y = (bounce & 0xFFu) | F_ACTIVE;
+    }
+    B.st2(SF_MA, slot, ma);
+}
+
+__global__ __launch_bounds__(256) void stream_hits_out(DScene sc, StreamBuf B, uint32_t n, zr_hit* __restrict__ out) {
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n) return;
+    const uint2 ki = B.ld2(SF_HIT_KI, slot);
+    zr_hit o;
+    if (ki.x != 0xFFFFFFFFu) {
+        Ray r; r.o = B.ld3(SF_RAY, slot); r.d = B.ld3(SF_RAY + 3, slot);
+        Rec rec;
+        object_rec(sc, ki.x, ki.y, r, B.ld(SF_HIT_T, slot), rec, true);
+        o.p[0] = rec.p.x; o.p[1] = rec.p.y; o.p[2] = rec.p.z;
+        o.normal[0] = rec.n.x; o.normal[1] = rec.n.y; o.normal[2] = rec.n.z;
+        o.tangent[0] = rec.tan.x; o.tangent[1] = rec.tan.y; o.tangent[2] = rec.tan.z;
+        o.bitangent[0] = rec.bit.x; o.bitangent[1] = rec.bit.y; o.bitangent[2] = rec.bit.z;
+        o.t = rec.t; o.u = rec.u; o.v = rec.v; o.mat = rec.mat; o.front_face = rec.front ? 1u : 0u;
+    } else {
+        for (int c = 0; c < 3; c++) { o.p[c] = 0; o.normal[c] = 0; o.tangent[c] = 0; o.bitangent[c] = 0; }
+        o.t = 0; o.u = 0; o.v = 0; o.mat = 0xFFFFFFFFu; o.front_face = 0;
+    }
+    out[slot] = o;
+}
+
 // ---- host-side launch helpers -----------------------------------------------------------------------------------
 size_t stream_ctl_words() { return 16 + 32 * ST_SHARDS; }
 size_t stream_overflow_bytes(int blocks) { return (size_t)blocks * ST_OVERFLOW * 64 * sizeof(SEntry); }
@@ -666,6 +702,23 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
     if (rounds_out) *rounds_out = cancelled ? -rounds : rounds;
+    return hipGetLastError();
+}
+
+// closest hits of n rays in [0.001, inf) through the EXTEND kernel; `pool` holds stream_pool_bytes(round_up(n, 64)) bytes
+hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
+                        void* pool, unsigned int* d_ctl, void* d_overflow, int extend_blocks, unsigned long long* gctr, bool generic,
+                        hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t P = (n + 63u) / 64u * 64u;
+    const size_t W = stream_ctl_words();
+    StreamBuf B = make_buf(pool, P, 1, n, n, nullptr, nullptr, d_ctl, d_ctl + (size_t)ST_MAX_POOLS * W, 0, P);
+    hipError_t e;
+    if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(stream_load_rays, dim3((P + 255) / 256), dim3(256), 0, stream, B, d_rays, n, seed, pixel, bounce);
+    const int eb = (int)(P / 64 < (uint32_t)extend_blocks ? P / 64 : (uint32_t)extend_blocks);
+    launch_extend<false>(sc, B, d_overflow, eb, gctr, generic, stream);
+    hipLaunchKernelGGL(stream_hits_out, dim3((n + 255) / 256), dim3(256), 0, stream, sc, B, n, d_out);
     return hipGetLastError();
 }
 

@@ -95,8 +95,7 @@ __global__ __launch_bounds__(64, WF_MIN_WAVES) void render_wavefront(DScene sc, 
         int slot = 0;
 
         auto start_traversal = [&]() {
-            idx_ = 1.0 / ray.d.x; idy_ = 1.0 / ray.d.y; idz_ = 1.0 / ray.d.z;
-            ox_ = ray.o.x * idx_; oy_ = ray.o.y * idy_; oz_ = ray.o.z * idz_;
+            slab_constants(ray.d.x, ray.o.x, idx_, ox_); slab_constants(ray.d.y, ray.o.y, idy_, oy_); slab_constants(ray.d.z, ray.o.z, idz_, oz_);
             tbest = INF; kbest = NONE; cur = 0; sp = 0; pa_meta = 0; pb_meta = 0; pend_i = 0;
             st = ST_NODE;
             if (COUNT) c_seg++;

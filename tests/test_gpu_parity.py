@@ -74,9 +74,12 @@ def test_radiance_matches_reference(name, ctx):
     print(f"{name}: max rel err {worst:.3e}, segments {ctr.segments}")
 
 
+@pytest.mark.parametrize("engine", ["extend", "pairs"])
 @pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0"])
-def test_hit_records_match_reference(name, ctx):
-    """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records."""
+def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
+    """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records, through both
+    traversal engines: the streaming pipeline's EXTEND kernel (4-wide quantised tree) and the pair-BVH walk."""
+    monkeypatch.setenv("ZR_TRACE_ENGINE", engine)
     fx = load_golden(name)
     m = fx["meta"]
     sc = gpu_scene(ctx, m["scene"], m["scene_args"])
@@ -101,6 +104,46 @@ def test_hit_records_match_reference(name, ctx):
     assert np.all(np.abs(hits["tangent"][wrote_uv] - recs[wrote_uv, 11:14]) < 1e-7)
     pairs = set(zip(recs[h, 14].astype(int).tolist(), hits["mat"][h].tolist()))
     assert len(pairs) == len({a for a, _ in pairs}) == len({b for _, b in pairs})
+
+
+@pytest.mark.parametrize("name", ["cfg3_small", "cfg2", "mix0"])
+def test_extend_adversarial_rays(name, ctx, monkeypatch):
+    """EXTEND's box tests are FP32, quantised and conservative; the pair walk uses plain FP32 boxes and the oracle FP64
+    ones.  Rays chosen to stress the conservative arithmetic — axis-aligned directions (zero components, both signs of
+    zero), origins on box planes and far away, tiny and huge direction scales — must give the same closest hit on all
+    three (the hit is decided by the FP64 primitive tests alone)."""
+    from oracle import zr_oracle_py as zo
+    scene, args = {"cfg3_small": ("cfg3", (200, 20, 256, 128))}.get(name, (name, ()))   # 8 000-triangle knot
+    ds = demo_scene(scene, args)
+    sc = gpu_scene(ctx, scene, args)
+    rng = np.random.default_rng(20260417)
+    n = 6000
+    o = rng.uniform(-6, 6, (n, 3))
+    d = rng.normal(size=(n, 3))
+    k = n // 6
+    for a in range(3):                       # one or two exactly-zero components, +0 and -0
+        d[a * k:(a + 1) * k, a] = 0.0
+        d[a * k:a * k + k // 2, a] = -0.0
+        d[a * k:a * k + k // 4, (a + 1) % 3] = 0.0
+    d[3 * k:4 * k] *= 1e-12                  # un-normalised directions, both extremes (t scales with 1/|d|)
+    d[4 * k:5 * k] *= 1e9
+    o[5 * k:5 * k + k // 2] *= 1e4           # far origins looking back at the scene
+    d[5 * k:5 * k + k // 2] = -o[5 * k:5 * k + k // 2] + rng.normal(size=(k // 2, 3))
+    o[5 * k + k // 2:] = np.round(o[5 * k + k // 2:] * 4) / 4   # origins on round coordinates (often on box planes)
+    rays = np.concatenate([o, d], axis=1)
+    monkeypatch.setenv("ZR_TRACE_ENGINE", "extend")
+    he = sc.trace(rays, seed=5, pixel=77, bounce=0)
+    monkeypatch.setenv("ZR_TRACE_ENGINE", "pairs")
+    hp = sc.trace(rays, seed=5, pixel=77, bounce=0)
+    ho = zo.OracleScene(ds.desc).trace(rays, seed=5, pixel=77, bounce=0)
+    assert (ho["mat"] != 0xFFFFFFFF).sum() > n // 20, "the probe rays barely hit the scene"
+    for got, tag in ((he, "extend"), (hp, "pairs")):
+        assert np.array_equal(got["mat"], ho["mat"]), f"{tag}: {(got['mat'] != ho['mat']).sum()} rays differ from the oracle"
+        h = ho["mat"] != 0xFFFFFFFF
+        assert np.all(rel_err(got["t"][h], ho["t"][h], 1e-300) < 1e-9), tag
+        near = h.copy()
+        near[5 * k:5 * k + k // 2] = False   # far origins: the sphere's discriminant cancels ~1e9:1 there, so fused and
+        assert np.all(np.abs(got["normal"][near] - ho["normal"][near]) < 1e-7), tag   # unfused FP64 differ at 1e-5 in p / r
 
 
 @pytest.mark.parametrize("name,region", [("cfg1", None), ("mix0", None), ("mix1", None), ("mix2", None),
