@@ -460,6 +460,7 @@ int main(int argc, char** argv) {
         double lo[3] = {clampf(box.x.min, clo, chi), clampf(box.y.min, clo, chi), clampf(box.z.min, clo, chi)};
         double hi[3] = {clampf(box.x.max, clo, chi), clampf(box.y.max, clo, chi), clampf(box.z.max, clo, chi)};
         std::vector<double> rays(n * 6), recs(n * 16);
+        const bool adversarial = std::getenv("ZR_TRACE_ADVERSARIAL") != nullptr;
         // map material pointers to first-seen ordinal so fixtures can compare material identity
         std::map<const material*, int> mat_id;
         probe_world world(*b.bvh);
@@ -472,12 +473,27 @@ int main(int argc, char** argv) {
                 o[c] = lo[c] - 0.25 * ext + 1.5 * ext * q[c];
                 t[c] = lo[c] + ext * q[3 + c];
             }
-            ray r(point3(o[0], o[1], o[2]), vec3(t[0] - o[0], t[1] - o[1], t[2] - o[2]));
+            double dd[3] = {t[0] - o[0], t[1] - o[1], t[2] - o[2]};
+            if (adversarial) {
+                // rays that stress the box arithmetic of a traversal: exactly-zero direction components (both signs of
+                // zero), tiny and large direction scales, origins on round coordinates, far origins
+                switch (k % 8) {
+                    case 0: dd[0] = 0.0; break;
+                    case 1: dd[1] = -0.0; break;
+                    case 2: dd[2] = 0.0; dd[0] = -0.0; break;
+                    case 3: for (double& v : dd) v *= 1e-12; break;
+                    case 4: for (double& v : dd) v *= 64.0; break;
+                    case 5: for (int c = 0; c < 3; c++) { o[c] = std::round(o[c] * 4.0) / 4.0; dd[c] = t[c] - o[c]; } break;
+                    case 6: for (int c = 0; c < 3; c++) { o[c] = t[c] + (o[c] - t[c]) * 4096.0; dd[c] = t[c] - o[c]; } break;
+                    default: break;
+                }
+            }
+            ray r(point3(o[0], o[1], o[2]), vec3(dd[0], dd[1], dd[2]));
             hit_record rec;
             probe_world::sample_segments() = 0;  // bounce 0 for the medium key
             bool h = world.hit(r, interval(0.001, infinity), rec);
             double* rr = &rays[k * 6];
-            rr[0] = o[0]; rr[1] = o[1]; rr[2] = o[2]; rr[3] = t[0] - o[0]; rr[4] = t[1] - o[1]; rr[5] = t[2] - o[2];
+            rr[0] = o[0]; rr[1] = o[1]; rr[2] = o[2]; rr[3] = dd[0]; rr[4] = dd[1]; rr[5] = dd[2];
             double* e = &recs[k * 16];
             if (h) {
                 int id;

@@ -44,6 +44,10 @@ TRACES = {
     "trace_cfg5": ("cfg5", 2048, 13, -30, 600, []),
     "trace_cfg3_small": ("cfg3", 2048, 14, -4, 4, [200, 20, 256, 128]),
     "trace_mesh0": ("mesh0", 4096, 15, -3, 4, []),
+    # adversarial rays (ZR_TRACE_ADVERSARIAL: zero direction components, tiny/large scales, round and far origins)
+    "trace_adv_mix0": ("mix0", 4096, 21, -6, 6, [], True),
+    "trace_adv_cfg2": ("cfg2", 4096, 22, -12, 12, [], True),
+    "trace_adv_cfg3_small": ("cfg3", 4096, 23, -4, 4, [200, 20, 256, 128], True),
 }
 
 
@@ -78,12 +82,20 @@ def main():
                 arrays["counts"] = np.load(pre + "_counts.npy")
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrays)
             print(name, meta)
-        for name, (scene, n, seed, clo, chi, extra) in TRACES.items():
+        for name, spec in TRACES.items():
+            scene, n, seed, clo, chi, extra = spec[:6]
+            adv = len(spec) > 6 and spec[6]
             if want and name not in want and scene not in want:
                 continue
             pre = os.path.join(tmp, name)
+            if adv:
+                os.environ["ZR_TRACE_ADVERSARIAL"] = "1"
+            else:
+                os.environ.pop("ZR_TRACE_ADVERSARIAL", None)
             meta = run("trace", scene, n, seed, pre, clo, chi, *extra)
+            os.environ.pop("ZR_TRACE_ADVERSARIAL", None)
             meta["scene_args"] = extra
+            meta["adversarial"] = bool(adv)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), rays=np.load(pre + "_rays.npy"),
                                 recs=np.load(pre + "_recs.npy"), meta=np.array(json.dumps(meta)))
             print(name, meta)

@@ -75,7 +75,8 @@ def test_radiance_matches_reference(name, ctx):
 
 
 @pytest.mark.parametrize("engine", ["extend", "pairs"])
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0"])
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0",
+                                  "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records, through both
     traversal engines: the streaming pipeline's EXTEND kernel (4-wide quantised tree) and the pair-BVH walk."""
@@ -88,9 +89,14 @@ def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     ref_hit = recs[:, 0] > 0
     got_hit = hits["mat"] != 0xFFFFFFFF
     assert np.array_equal(ref_hit, got_hit), f"{int((ref_hit != got_hit).sum())} rays disagree on hit/miss"
-    h = ref_hit
     tol = 1e-9
-    assert np.all(rel_err(hits["t"][h], recs[h, 1], 1e-12) < tol)
+    assert np.all(rel_err(hits["t"][ref_hit], recs[ref_hit, 1], 1e-12) < tol)
+    h = ref_hit.copy()
+    if m.get("adversarial"):
+        # class 6 of the adversarial rays starts 4096 scene sizes away: o + t d then carries |o| 2^-53 ~ 1e-11 of absolute
+        # error per operation and a sphere's discriminant cancels 1e9:1, so p and the normal are compared for the other
+        # classes only (hit/miss, t and the material are compared for all)
+        h[np.arange(len(h)) % 8 == 6] = False
     assert np.all(np.abs(hits["p"][h] - recs[h, 2:5]) <= tol * (1 + np.abs(recs[h, 2:5])))
     assert np.all(np.abs(hits["normal"][h] - recs[h, 5:8]) < 1e-7)
     assert np.array_equal(hits["front_face"][h], recs[h, 8].astype(np.uint32))

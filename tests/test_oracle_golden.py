@@ -42,7 +42,8 @@ def test_oracle_matches_reference_radiance(name, built):
         assert np.array_equal(counts, fx["counts"])
 
 
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0"])
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0",
+                                  "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_oracle_matches_reference_hit_records(name, built):
     """world.hit() known answers: t, p, normal, front_face, u, v, tangent and the first scatter's attenuation."""
     from oracle import zr_oracle_py as zo
