@@ -908,6 +908,7 @@ public:
     bool use_albedo_buffer = false, use_normal_buffer = false, use_z_depth_buffer = false, use_reflection = false, use_refraction = false;
     std::vector<color> render_accumulator;
     std::vector<color> albedo_buffer, normal_buffer, z_depth_buffer;  // first-hit passes (camera.hpp:81-83), filled when their flag is set
+    std::vector<color> reflection_buffer, refraction_buffer;          // second-path split (camera.hpp:84-85, 490-517), filled when either flag is set
     std::atomic<int> lines_rendered{0};
     uint64_t seed = 0x5EED0000ull;  // extension: the reference cannot be seeded (common.hpp:30-31)
     int device = 0;                 // extension: HIP device ordinal
@@ -918,6 +919,8 @@ public:
         albedo_buffer.assign(render_accumulator.size(), color(0, 0, 0));
         normal_buffer.assign(render_accumulator.size(), color(0, 0, 0));
         z_depth_buffer.assign(render_accumulator.size(), color(0, 0, 0));
+        reflection_buffer.assign(render_accumulator.size(), color(0, 0, 0));
+        refraction_buffer.assign(render_accumulator.size(), color(0, 0, 0));
         current_samples_count = 0; lines_rendered = 0;
     }
 
@@ -956,6 +959,15 @@ public:
                 rc = zr_render_aov(ctx, sc, &zc, seed, nullptr, &ap, use_albedo_buffer ? reinterpret_cast<double*>(albedo_buffer.data()) : nullptr,
                                    use_normal_buffer ? reinterpret_cast<double*>(normal_buffer.data()) : nullptr,
                                    use_z_depth_buffer ? reinterpret_cast<double*>(z_depth_buffer.data()) : nullptr);
+            }
+            if (rc == ZR_OK && (use_reflection || use_refraction)) {
+                // camera.hpp:490: either flag runs the second path and fills BOTH frames; the beauty image above is what the
+                // reference's loop produces with the flags on (same stream prefix), so it is not rendered again
+                const size_t npx = (size_t)image_width * image_height;
+                reflection_buffer.assign(npx, color(0, 0, 0));
+                refraction_buffer.assign(npx, color(0, 0, 0));
+                rc = zr_render_passes(ctx, sc, &zc, &zenv, seed, nullptr, nullptr, reinterpret_cast<double*>(reflection_buffer.data()),
+                                      reinterpret_cast<double*>(refraction_buffer.data()));
             }
         }
         if (rc != ZR_OK && rc != ZR_E_CANCELLED) std::cerr << "[zenith] render failed: " << zr_last_error() << "\n";

@@ -261,6 +261,16 @@ typedef struct zr_aov_params {
 int zr_render_aov(zr_ctx*, const zr_scene*, const zr_camera*, uint64_t seed, const zr_region* region, const zr_aov_params*,
                   double* out_albedo, double* out_normal, double* out_zdepth);
 
+/* The render with the reflection / refraction split enabled (camera.hpp:490-517, use_reflection || use_refraction): per
+ * primary sample, after the beauty path, the first hit is scattered a second time (fresh draws: the sample's stream just
+ * continues) and a second path of max_depth - 1 bounces is traced; its radiance, luma-clamped to 2.0 (0.2126 |c|), times
+ * the attenuation goes to the reflection frame when the scattered direction is within acos(0.9) of the mirror direction,
+ * else to the refraction frame when it points below the surface.  Frames are W*H*3 doubles, means over spp (light_scale,
+ * camera.hpp:531-533); a NULL buffer skips that frame.  out_beauty equals zr_render's image.  zr_get_counters afterwards
+ * reports primary samples, segments (both paths), hits and RNG draws of the call. */
+int zr_render_passes(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed, const zr_region* region,
+                     double* out_beauty, double* out_reflection, double* out_refraction);
+
 /* counters + device time of the last render on this context (synchronises the context's stream) */
 int zr_get_counters(zr_ctx*, zr_counters*);
 /* drains the log of render-kernel launch durations (ms, measured with HIP events on the launch stream) recorded

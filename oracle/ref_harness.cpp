@@ -237,6 +237,31 @@ struct ref_camera {
         }
     }
 
+    // one primary sample with the reflection / refraction split enabled: camera.hpp:455-461 (beauty), 490-517 (the
+    // first hit is scattered AGAIN, with fresh draws, and a second path is traced), 520 (miss)
+    void passes_sample(int i, int j, const hittable& world, const EnvironmentSettings& env, color& beauty, color& reflection,
+                       color& refraction) const {
+        ray r = get_ray(i, j);
+        hit_record rec;
+        if (world.hit(r, interval(0.001, infinity), rec)) {
+            beauty += ray_color_from_hit(r, rec, world, c.max_depth, env);
+            ray scattered;
+            color attenuation;
+            if (rec.mat->scatter(r, rec, attenuation, scattered)) {
+                color scattered_color = ray_color(scattered, world, c.max_depth - 1, env);
+                double luma = 0.2126 * scattered_color.length();
+                double max_luma = 2.0;
+                if (luma > max_luma) scattered_color *= (max_luma / luma);
+                vec3 reflected_dir = reflect(unit_vector(r.direction()), unit_vector(rec.normal));
+                bool is_specular = dot(unit_vector(scattered.direction()), reflected_dir) > 0.9;
+                if (is_specular) reflection += attenuation * scattered_color;
+                else if (dot(scattered.direction(), rec.normal) < 0) refraction += attenuation * scattered_color;
+            }
+        } else {
+            beauty += background(r, env);
+        }
+    }
+
     // one primary sample of pixel (i, j): the body of the sample loop, camera.hpp:455-461,520
     color sample(int i, int j, const hittable& world, const EnvironmentSettings& env) const {
         ray r = get_ray(i, j);
@@ -353,6 +378,7 @@ static int usage() {
                  "  zenith_ref time   <scene> <xstep> <ystep> <spp|0> <threads> [a0 a1 a2 a3]\n"
                  "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> <clamp_lo> <clamp_hi> [a0 a1 a2 a3]\n"
                  "  zenith_ref aov    <scene> <x0> <y0> <w> <h> <zmax> <out_prefix> - [a0 a1 a2 a3]\n"
+                 "  zenith_ref passes <scene> <x0> <y0> <w> <h> <spp|0> <out_prefix> [a0 a1 a2 a3]\n"
                  "  zenith_ref texels <w> <h> <out.npy>\n");
     return 2;
 }
@@ -422,6 +448,46 @@ int main(int argc, char** argv) {
         write_npy(out + "_zdepth.npy", "<f8", {(size_t)h, (size_t)w, 3}, Z.data(), Z.size() * 8);
         std::printf("{\"scene\": \"%s\", \"x0\": %d, \"y0\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"aux\": %d, \"zmax\": %.17g, \"seed\": %llu}\n",
                     argv[2], x0, y0, w, h, spp, actual, zmax, (unsigned long long)b.s.seed);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "passes" && argc >= 9) {
+        // zenith_ref passes <scene> <x0> <y0> <w> <h> <spp|0> <out_prefix> [a0..a3]: beauty / reflection / refraction
+        // tiles with use_reflection = use_refraction = true (camera.hpp:490-517, 531-533)
+        built_scene b;
+        if (!build(b, argv[2], iarg(9, 0), iarg(10, 0), iarg(11, 0), iarg(12, 0))) return usage();
+        int x0 = iarg(3, 0), y0 = iarg(4, 0), w = iarg(5, 1), h = iarg(6, 1), spp = iarg(7, 0);
+        std::string out = argv[8];
+        ref_camera cam; cam.c = b.s.cam;
+        if (spp > 0) cam.c.samples_per_pixel = spp;
+        cam.initialize();
+        spp = cam.c.samples_per_pixel;
+        probe_world world(*b.bvh);
+        std::vector<double> B((size_t)w * h * 3), R((size_t)w * h * 3), F((size_t)w * h * 3);
+        zr_oracle_tls.draws = 0; seg_tls.segments = 0;
+        for (int jj = 0; jj < h; jj++)
+            for (int ii = 0; ii < w; ii++) {
+                int i = x0 + ii, j = y0 + jj;
+                color cb(0, 0, 0), cr(0, 0, 0), cf(0, 0, 0);
+                for (int s2 = 0; s2 < spp; s2++) {
+                    zr_oracle_seed(b.s.seed, (uint64_t)j * cam.c.image_width + i, (uint64_t)s2);
+                    probe_world::sample_segments() = 0;
+                    cam.passes_sample(i, j, world, b.s.env, cb, cr, cf);
+                }
+                double sc = 1.0 / spp;  // light_scale, camera.hpp:436-437
+                color bm = cb * sc, rm = cr * sc, fm = cf * sc;
+                size_t o = ((size_t)jj * w + ii) * 3;
+                B[o] = bm.x(); B[o + 1] = bm.y(); B[o + 2] = bm.z();
+                R[o] = rm.x(); R[o + 1] = rm.y(); R[o + 2] = rm.z();
+                F[o] = fm.x(); F[o + 1] = fm.y(); F[o + 2] = fm.z();
+            }
+        write_npy(out + "_beauty.npy", "<f8", {(size_t)h, (size_t)w, 3}, B.data(), B.size() * 8);
+        write_npy(out + "_reflection.npy", "<f8", {(size_t)h, (size_t)w, 3}, R.data(), R.size() * 8);
+        write_npy(out + "_refraction.npy", "<f8", {(size_t)h, (size_t)w, 3}, F.data(), F.size() * 8);
+        std::printf("{\"scene\": \"%s\", \"x0\": %d, \"y0\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"seed\": %llu, \"segments\": %llu, \"draws\": %llu}\n",
+                    argv[2], x0, y0, w, h, spp, (unsigned long long)b.s.seed, (unsigned long long)seg_tls.segments,
+                    (unsigned long long)zr_oracle_tls.draws);
         cleanup(b);
         return 0;
     }

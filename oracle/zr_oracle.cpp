@@ -765,6 +765,34 @@ V3 sample_radiance(const Scene& sc, const Cam& cam, const zr_env& env, int i, in
     return L;
 }
 
+// one primary sample with the reflection / refraction split (camera.hpp:455-461, 490-517, 520): the first hit is scattered a
+// second time, with the draws that follow the beauty path on the same stream, and a second path is traced
+void sample_passes(const Scene& sc, const Cam& cam, const zr_env& env, int i, int j, Rng& g, Counters* c, V3& beauty, V3& reflection,
+                   V3& refraction) {
+    Ray r = cam.get_ray(i, j, g);
+    Rec rec;
+    bool h = sc.world_hit(r, 0.001, kInf, rec, g, c);
+    g.bounce++;
+    if (!h) { beauty = beauty + background(sc, env, r); return; }
+    {   // ray_color_from_hit, camera.hpp:989-1004
+        V3 L = sc.emitted(rec);
+        Ray out; V3 att;
+        if (sc.scatter(r, rec, att, out, g)) L = L + att * ray_color(sc, env, out, cam.c.max_depth - 1, g, c);
+        beauty = beauty + L;
+    }
+    Ray scattered; V3 attenuation;
+    if (sc.scatter(r, rec, attenuation, scattered, g)) {
+        V3 scol = ray_color(sc, env, scattered, cam.c.max_depth - 1, g, c);
+        double luma = 0.2126 * len(scol);
+        const double max_luma = 2.0;
+        if (luma > max_luma) scol = scol * (max_luma / luma);
+        V3 reflected_dir = reflect(unit(r.d), unit(rec.n));
+        bool is_specular = dot(unit(scattered.d), reflected_dir) > 0.9;
+        if (is_specular) reflection = reflection + attenuation * scol;
+        else if (dot(scattered.d, rec.n) < 0) refraction = refraction + attenuation * scol;
+    }
+}
+
 void to_hit(const Rec& rec, bool h, zr_hit& o) {
     std::memset(&o, 0, sizeof(o));
     o.mat = 0xFFFFFFFFu;
@@ -839,6 +867,34 @@ int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t
             ctr->media_tested += c.med; ctr->hits += c.hits; ctr->rng_draws += c.draws;
         }
     }
+    return ZR_OK;
+}
+
+// beauty / reflection / refraction with both split flags on (camera.hpp:490-517, 531-533); outputs region-sized h*w*3
+int zro_render_passes(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t seed, const zr_region* region, double* beauty,
+                      double* reflection, double* refraction, zr_counters* ctr) {
+    const Scene& sc = *(Scene*)scene;
+    Cam cam; cam.c = *cam_in; cam.initialize();
+    const int W = cam.c.image_width, spp = cam.c.samples_per_pixel;
+    const int x0 = region->x0, y0 = region->y0, w = region->w, h = region->h;
+    Counters c;
+    for (int jj = 0; jj < h; jj++)
+        for (int ii = 0; ii < w; ii++) {
+            const int i = x0 + ii, j = y0 + jj;
+            V3 cb(0, 0, 0), cr(0, 0, 0), cf(0, 0, 0);
+            for (int s = 0; s < spp; s++) {
+                Rng g; g.key = zr_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s);
+                sample_passes(sc, cam, *env, i, j, g, &c, cb, cr, cf);
+                c.primary++; c.draws += g.draws;
+            }
+            const double scl = 1.0 / spp;
+            const size_t o = ((size_t)jj * w + ii) * 3;
+            V3 bm = cb * scl, rm = cr * scl, fm = cf * scl;
+            if (beauty) { beauty[o] = bm.x(); beauty[o + 1] = bm.y(); beauty[o + 2] = bm.z(); }
+            if (reflection) { reflection[o] = rm.x(); reflection[o + 1] = rm.y(); reflection[o + 2] = rm.z(); }
+            if (refraction) { refraction[o] = fm.x(); refraction[o + 1] = fm.y(); refraction[o + 2] = fm.z(); }
+        }
+    if (ctr) { std::memset(ctr, 0, sizeof(*ctr)); ctr->primary_samples = c.primary; ctr->segments = c.segments; ctr->rng_draws = c.draws; ctr->hits = c.hits; }
     return ZR_OK;
 }
 

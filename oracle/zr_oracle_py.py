@@ -38,6 +38,8 @@ def load():
     lib.zro_render.argtypes = [vp, C.POINTER(capi.Camera), C.POINTER(capi.Env), C.c_uint64, C.POINTER(capi.Region),
                                C.c_int, vp, vp, vp, C.POINTER(capi.Counters)]
     lib.zro_render_aov.argtypes = [vp, C.POINTER(capi.Camera), C.c_uint64, C.POINTER(capi.Region), C.c_double, vp, vp, vp]
+    lib.zro_render_passes.argtypes = [vp, C.POINTER(capi.Camera), C.POINTER(capi.Env), C.c_uint64, C.POINTER(capi.Region), vp, vp, vp,
+                                      C.POINTER(capi.Counters)]
     lib.zro_trace.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     lib.zro_scatter.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     _lib = lib
@@ -74,6 +76,14 @@ class OracleScene:
         self.lib.zro_render_aov(self._s, C.byref(camera), C.c_uint64(seed), C.byref(region), float(zmax), outs[0].ctypes.data,
                                 outs[1].ctypes.data, outs[2].ctypes.data)
         return outs
+
+    def render_passes(self, camera, env, seed, region):
+        """beauty / reflection / refraction tiles (region-sized) + counters"""
+        outs = [np.zeros((region.h, region.w, 3), dtype=np.float64) for _ in range(3)]
+        ctr = capi.Counters()
+        self.lib.zro_render_passes(self._s, C.byref(camera), C.byref(env), C.c_uint64(seed), C.byref(region), outs[0].ctypes.data,
+                                   outs[1].ctypes.data, outs[2].ctypes.data, C.byref(ctr))
+        return outs, ctr
 
     def trace(self, rays, tmin=0.001, tmax=float("inf"), seed=1, pixel=0x7ACE, bounce=0):
         rays = np.ascontiguousarray(rays, dtype=np.float64)

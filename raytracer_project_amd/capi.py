@@ -120,7 +120,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
 ]
 
@@ -155,6 +155,7 @@ def load():
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
     lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
+    lib.zr_render_passes.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), vp, vp, vp]
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.zr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), i32]
     lib.zr_trace.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, u64, u64, C.c_uint32, vp]
@@ -301,6 +302,15 @@ class Scene:
         rp = C.byref(region) if region is not None else None
         _check(self.lib.zr_render_aov(self.ctx._c, self._s, C.byref(camera), C.c_uint64(seed), rp, C.byref(ap),
                                       outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data))
+        return outs
+
+    def render_passes(self, camera, env, seed, region=None):
+        """beauty / reflection / refraction frames with the split enabled (camera.hpp:490-517): three (H, W, 3) float64 frames"""
+        h, w = camera.image_height, camera.image_width
+        outs = [np.zeros((h, w, 3), dtype=np.float64) for _ in range(3)]
+        rp = C.byref(region) if region is not None else None
+        _check(self.lib.zr_render_passes(self.ctx._c, self._s, C.byref(camera), C.byref(env), C.c_uint64(seed), rp,
+                                         outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data))
         return outs
 
     def render_device(self, camera, env, seed, d_ptr, stream=0, region=None, count=False):

@@ -1094,6 +1094,51 @@ int zr_render_aov(zr_ctx* c, const zr_scene* s, const zr_camera* cam, uint64_t s
     return ZR_OK;
 }
 
+int zr_render_passes(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const zr_region* region,
+                     double* out_beauty, double* out_reflection, double* out_refraction) {
+    if (!c || !s || !cam || !env) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_render_passes");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    if (!out_beauty && !out_reflection && !out_refraction) return ZR_OK;
+    HIP_OK(hipSetDevice(c->device));
+    Plan plan;
+    int rc = make_plan(*cam, region, plan);
+    if (rc) return rc;
+    zr::DCamera dc; make_camera(*cam, dc);
+    zr::DEnv de; make_env(*env, de);
+    if (de.mode > ZR_ENV_SOLID_COLOR) return fail(ZR_E_INVALID, "unknown environment mode %u", de.mode);
+    if (de.mode == ZR_ENV_HDR_MAP && de.hdr_tex != ZR_NO_TEXTURE && de.hdr_tex >= s->textures.size()) return fail(ZR_E_INVALID, "environment texture id out of range");
+    const size_t npx = (size_t)plan.W * plan.H;
+    DevBuf<double> d_b, d_r, d_f;
+    if (out_beauty) { if ((rc = d_b.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_b.p, 0, npx * 24, c->stream)); }
+    if (out_reflection) { if ((rc = d_r.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_r.p, 0, npx * 24, c->stream)); }
+    if (out_refraction) { if ((rc = d_f.alloc(npx * 3))) return rc; HIP_OK(hipMemsetAsync(d_f.p, 0, npx * 24, c->stream)); }
+    std::vector<int32_t> tiles = plan.tiles;
+    if ((rc = c->d_tiles.upload(tiles))) return rc;
+    zr::WorkDesc wd;
+    wd.tiles = c->d_tiles.p; wd.n_tiles = (int32_t)tiles.size(); wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
+    wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
+    wd.lanes_per_pixel = 64; while (wd.lanes_per_pixel > dc.spp) wd.lanes_per_pixel >>= 1;
+    c->render_id++; c->last_counted = true; c->last_rounds = 0;
+    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_OK(zr::launch_passes(s->ds, dc, de, seed, wd, d_b.p, d_r.p, d_f.p, c->d_ctr.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<double> frame(npx * 3);
+    auto copy_out = [&](DevBuf<double>& d, double* out) -> int {
+        if (!out) return ZR_OK;
+        HIP_OK(hipMemcpy(frame.data(), d.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int32_t t : plan.tiles) {
+            int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+            int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+            for (int y = ya; y < yb; y++)
+                if (xb > xa) std::memcpy(out + ((size_t)y * plan.W + xa) * 3, frame.data() + ((size_t)y * plan.W + xa) * 3, (size_t)(xb - xa) * 3 * sizeof(double));
+        }
+        return ZR_OK;
+    };
+    if ((rc = copy_out(d_b, out_beauty)) || (rc = copy_out(d_r, out_reflection)) || (rc = copy_out(d_f, out_refraction))) return rc;
+    return ZR_OK;
+}
+
 int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (!c || !out) return fail(ZR_E_INVALID, "null argument");
     HIP_OK(hipSetDevice(c->device));

@@ -21,32 +21,20 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     return __hiloint2double(hi, lo);
 }
 
-// radiance of one primary sample: camera.hpp:455-461,520 + ray_color_from_hit 989-1004 + ray_color 928-986
+// ray_color(r, depth), camera.hpp:928-986: its own L / beta start from (0, 1); the loop index restarts at 0
 template <bool COUNT>
-__device__ inline V3 sample_radiance(const DScene& sc, const DCamera& cam, const DEnv& env, int i, int j, Rng& g, uint32_t* stack,
-                                     int stride, Counters& ctr, uint32_t& segments, uint32_t& hits) {
-    Ray r = camera_ray(cam, i, j, g);
-    double t; uint32_t kind, idx;
-    segments++;
-    bool h = closest_hit<COUNT>(sc, r, 0.001, g, stack, stride, t, kind, idx, ctr);
-    g.bounce++;
-    if (!h) return background(sc, env, r.d);
-    hits++;
-    Rec rec;
-    object_rec(sc, kind, idx, r, t, rec);
-    V3 L0 = emitted(sc, rec);
-    V3 att0; Ray cur;
-    if (!scatter(sc, r, rec, att0, cur, g)) return L0;
-    // ray_color(scattered, depth - 1): its own L / beta start from (0, 1); loop index i restarts at 0
+__device__ inline V3 path_radiance(const DScene& sc, const DEnv& env, Ray cur, int depth, Rng& g, uint32_t* stack, int stride, Counters& ctr,
+                                   uint32_t& segments, uint32_t& hits) {
     V3 L = mk(0, 0, 0), beta = mk(1, 1, 1);
-    const int depth = cam.max_depth - 1;
     bool missed = false;
     for (int b = 0; b < depth; b++) {
+        double t; uint32_t kind, idx;
         segments++;
-        h = closest_hit<COUNT>(sc, cur, 0.001, g, stack, stride, t, kind, idx, ctr);
+        bool h = closest_hit<COUNT>(sc, cur, 0.001, g, stack, stride, t, kind, idx, ctr);
         g.bounce++;
         if (!h) { missed = true; break; }
         hits++;
+        Rec rec;
         object_rec(sc, kind, idx, cur, t, rec);
         L = L + beta * emitted(sc, rec);
         V3 att; Ray out;
@@ -62,7 +50,58 @@ __device__ inline V3 sample_radiance(const DScene& sc, const DCamera& cam, const
         }
     }
     if (missed) L = L + beta * background(sc, env, cur.d);
-    return L0 + att0 * L;
+    return L;
+}
+
+// radiance of one primary sample: camera.hpp:455-461,520 + ray_color_from_hit 989-1004
+template <bool COUNT>
+__device__ inline V3 sample_radiance(const DScene& sc, const DCamera& cam, const DEnv& env, int i, int j, Rng& g, uint32_t* stack,
+                                     int stride, Counters& ctr, uint32_t& segments, uint32_t& hits) {
+    Ray r = camera_ray(cam, i, j, g);
+    double t; uint32_t kind, idx;
+    segments++;
+    bool h = closest_hit<COUNT>(sc, r, 0.001, g, stack, stride, t, kind, idx, ctr);
+    g.bounce++;
+    if (!h) return background(sc, env, r.d);
+    hits++;
+    Rec rec;
+    object_rec(sc, kind, idx, r, t, rec);
+    V3 L0 = emitted(sc, rec);
+    V3 att0; Ray cur;
+    if (!scatter(sc, r, rec, att0, cur, g)) return L0;
+    return L0 + att0 * path_radiance<COUNT>(sc, env, cur, cam.max_depth - 1, g, stack, stride, ctr, segments, hits);
+}
+
+// one primary sample with the reflection / refraction split on (camera.hpp:455-461, 490-517, 520): after the beauty path
+// the first hit is scattered AGAIN, with the draws that follow on the same stream, and a second path is traced
+template <bool COUNT>
+__device__ inline void sample_passes(const DScene& sc, const DCamera& cam, const DEnv& env, int i, int j, Rng& g, uint32_t* stack, int stride,
+                                     Counters& ctr, uint32_t& segments, uint32_t& hits, V3& beauty, V3& reflection, V3& refraction) {
+    Ray r = camera_ray(cam, i, j, g);
+    double t; uint32_t kind, idx;
+    segments++;
+    bool h = closest_hit<COUNT>(sc, r, 0.001, g, stack, stride, t, kind, idx, ctr);
+    g.bounce++;
+    if (!h) { beauty = beauty + background(sc, env, r.d); return; }
+    hits++;
+    Rec rec;
+    object_rec(sc, kind, idx, r, t, rec);
+    {
+        V3 L0 = emitted(sc, rec);
+        V3 att0; Ray cur;
+        if (scatter(sc, r, rec, att0, cur, g)) L0 = L0 + att0 * path_radiance<COUNT>(sc, env, cur, cam.max_depth - 1, g, stack, stride, ctr, segments, hits);
+        beauty = beauty + L0;
+    }
+    V3 att; Ray scattered;
+    if (scatter(sc, r, rec, att, scattered, g)) {
+        V3 scol = path_radiance<COUNT>(sc, env, scattered, cam.max_depth - 1, g, stack, stride, ctr, segments, hits);
+        const double luma = 0.2126 * len(scol), max_luma = 2.0;   // firefly clamp, camera.hpp:499-503
+        if (luma > max_luma) scol = scol * (max_luma / luma);
+        const V3 reflected_dir = reflect(unit(r.d), unit(rec.n));
+        const bool is_specular = dot(unit(scattered.d), reflected_dir) > 0.9;
+        if (is_specular) reflection = reflection + att * scol;
+        else if (dot(scattered.d, rec.n) < 0) refraction = refraction + att * scol;
+    }
 }
 
 template <bool COUNT>
@@ -117,6 +156,59 @@ __global__ __launch_bounds__(ZR_BLOCK) void render_pixels(DScene sc, DCamera cam
         atomicAdd(&gctr[4], (unsigned long long)ctr.tri);
         atomicAdd(&gctr[5], (unsigned long long)ctr.cube);
         atomicAdd(&gctr[6], (unsigned long long)ctr.med);
+        atomicAdd(&gctr[7], (unsigned long long)hits);
+        atomicAdd(&gctr[8], (unsigned long long)draws);
+    }
+}
+
+// beauty + reflection + refraction frames (use_reflection / use_refraction on): same pixel-group layout as render_pixels
+__global__ __launch_bounds__(ZR_BLOCK) void passes_pixels(DScene sc, DCamera cam, DEnv env, uint64_t seed, WorkDesc wd, double* __restrict__ out_beauty,
+                                                           double* __restrict__ out_reflection, double* __restrict__ out_refraction,
+                                                           unsigned long long* __restrict__ gctr) {
+    __shared__ uint32_t lds_stack[ZR_STACK_DEPTH * ZR_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const int L = wd.lanes_per_pixel;
+    const int groups_per_block = ZR_BLOCK / L;
+    const int group = threadIdx.x / L, lane_in_group = threadIdx.x % L;
+    const long long q = (long long)blockIdx.x * groups_per_block + group;
+    const int tpix = wd.tile_size * wd.tile_size;
+    bool active = q < (long long)wd.n_tiles * tpix;
+    int px = 0, py = 0;
+    if (active) {
+        int tile = wd.tiles[q / tpix];
+        int local = (int)(q % tpix);
+        px = (tile % wd.tiles_x) * wd.tile_size + local % wd.tile_size;
+        py = (tile / wd.tiles_x) * wd.tile_size + local / wd.tile_size;
+        active = px >= wd.x0 && px < wd.x1 && py >= wd.y0 && py < wd.y1;
+    }
+    V3 sb = mk(0, 0, 0), sr = mk(0, 0, 0), sf = mk(0, 0, 0);
+    Counters ctr = {0, 0, 0, 0, 0};
+    uint32_t segments = 0, hits = 0, nsamp = 0;
+    uint64_t draws = 0;
+    if (active) {
+        const uint64_t pixel = (uint64_t)py * (uint64_t)cam.W + (uint64_t)px;
+        for (int s = lane_in_group; s < cam.spp; s += L) {
+            Rng g; g.key = zr_stream_key(seed, pixel, (uint64_t)s); g.k = 0; g.bounce = 0;
+            sample_passes<true>(sc, cam, env, px, py, g, stack, ZR_BLOCK, ctr, segments, hits, sb, sr, sf);
+            nsamp++;
+            draws += g.k;
+        }
+    }
+    for (int m = 1; m < L; m <<= 1) {
+        sb.x += shfl_xor_f64(sb.x, m); sb.y += shfl_xor_f64(sb.y, m); sb.z += shfl_xor_f64(sb.z, m);
+        sr.x += shfl_xor_f64(sr.x, m); sr.y += shfl_xor_f64(sr.y, m); sr.z += shfl_xor_f64(sr.z, m);
+        sf.x += shfl_xor_f64(sf.x, m); sf.y += shfl_xor_f64(sf.y, m); sf.z += shfl_xor_f64(sf.z, m);
+    }
+    if (active && lane_in_group == 0) {
+        const double scale = 1.0 / cam.spp;  // light_scale, camera.hpp:436-437, 531-533
+        const size_t o = ((size_t)py * cam.W + px) * 3;
+        if (out_beauty) { out_beauty[o] = sb.x * scale; out_beauty[o + 1] = sb.y * scale; out_beauty[o + 2] = sb.z * scale; }
+        if (out_reflection) { out_reflection[o] = sr.x * scale; out_reflection[o + 1] = sr.y * scale; out_reflection[o + 2] = sr.z * scale; }
+        if (out_refraction) { out_refraction[o] = sf.x * scale; out_refraction[o + 1] = sf.y * scale; out_refraction[o + 2] = sf.z * scale; }
+    }
+    if (active) {
+        atomicAdd(&gctr[0], (unsigned long long)nsamp);
+        atomicAdd(&gctr[1], (unsigned long long)segments);
         atomicAdd(&gctr[7], (unsigned long long)hits);
         atomicAdd(&gctr[8], (unsigned long long)draws);
     }
@@ -227,6 +319,17 @@ hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     double3 cu = make_double3(uvw9[0], uvw9[1], uvw9[2]), cv = make_double3(uvw9[3], uvw9[4], uvw9[5]), cw = make_double3(uvw9[6], uvw9[7], uvw9[8]);
     hipLaunchKernelGGL(aov_pixels, dim3((unsigned)blocks), dim3(ZR_BLOCK), 0, stream, sc, cam, seed, wd, aux, zmax, cu, cv, cw, out_albedo, out_normal, out_zdepth);
+    return hipGetLastError();
+}
+
+hipError_t launch_passes(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out_beauty,
+                         double* out_reflection, double* out_refraction, unsigned long long* gctr, hipStream_t stream) {
+    const int groups_per_block = ZR_BLOCK / wd.lanes_per_pixel;
+    const long long pixels = (long long)wd.n_tiles * wd.tile_size * wd.tile_size;
+    const long long blocks = (pixels + groups_per_block - 1) / groups_per_block;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(passes_pixels, dim3((unsigned)blocks), dim3(ZR_BLOCK), 0, stream, sc, cam, env, seed, wd, out_beauty, out_reflection, out_refraction, gctr);
     return hipGetLastError();
 }
 

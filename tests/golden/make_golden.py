@@ -59,6 +59,14 @@ AOVS = {
     "aov_mesh0": ("mesh0", 0, 0, 96, 64, 9.0, []),
 }
 
+# beauty / reflection / refraction with the split flags on (camera.hpp:490-517): (scene, x0, y0, w, h, spp, scene args)
+PASSES = {
+    "passes_mix0": ("mix0", 0, 0, 96, 64, 16, []),
+    "passes_mix2": ("mix2", 0, 0, 64, 48, 16, []),
+    "passes_cfg2": ("cfg2", 560, 280, 48, 32, 32, []),
+    "passes_cfg5": ("cfg5", 150, 350, 32, 24, 32, []),
+}
+
 
 def run(*args):
     p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
@@ -107,6 +115,15 @@ def main():
             meta["scene_args"] = extra
             np.savez_compressed(os.path.join(HERE, name + ".npz"), albedo=np.load(pre + "_albedo.npy"), normal=np.load(pre + "_normal.npy"),
                                 zdepth=np.load(pre + "_zdepth.npy"), meta=np.array(json.dumps(meta)))
+            print(name, meta)
+        for name, (scene, x0, y0, w, h, spp, extra) in PASSES.items():
+            if want and name not in want and scene not in want:
+                continue
+            pre = os.path.join(tmp, name)
+            meta = run("passes", scene, x0, y0, w, h, spp, pre, *extra)
+            meta["scene_args"] = extra
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), beauty=np.load(pre + "_beauty.npy"), reflection=np.load(pre + "_reflection.npy"),
+                                refraction=np.load(pre + "_refraction.npy"), meta=np.array(json.dumps(meta)))
             print(name, meta)
         if not want or "texels" in want:
             out = os.path.join(tmp, "texels.npy")
