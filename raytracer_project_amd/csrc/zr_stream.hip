@@ -40,12 +40,6 @@ namespace zr {
 #ifndef ST_FETCH_MIN
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
-#ifndef ZR_EXTEND_DUAL_DEFAULT
-#define ZR_EXTEND_DUAL_DEFAULT 0
-#endif
-#ifndef ST_FETCH_MIN_DUAL
-#define ST_FETCH_MIN_DUAL 24 /* lanes with an idle ray that trigger a refill in the two-rays-per-lane EXTEND */
-#endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
 #define ST_LDS_STACK 12
@@ -386,220 +380,6 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     }
 }
 
-// ---- EXTEND, two rays per lane ---------------------------------------------------------------------------------------
-// stream_extend runs its NODE phases with ~30 and its LEAF phases with ~26 of 64 lanes (a lane whose ray waits for the
-// other phase idles), and the kernel is VALU-bound.  Here every lane carries TWO rays: a lane takes part in a phase when
-// either of its rays is ready for it, which fills the exec mask of every phase further at the price of selecting the
-// working ray (a few v_cndmask per state word the phase touches).  Only for worlds of bare triangles and spheres
-// (the state of two rays + the generic leaf code would not fit 128 VGPRs).
-#ifndef ST_LDS_STACK_DUAL
-#define ST_LDS_STACK_DUAL 8
-#endif
-#define ST_OVERFLOW_DUAL (ZR_STACK_DEPTH - ST_LDS_STACK_DUAL)
-struct XRay {
-    uint32_t slot;
-    Ray ray;
-    float idx, idy, idz, clx, cly, clz, chx, chy, chz;
-    double tbest;
-    float tbest_f;
-    uint32_t kbest, ibest, cur, pend_i;
-    int sp, st;
-};
-#define ZR_X_EACH(F) F(slot) F(ray.o.x) F(ray.o.y) F(ray.o.z) F(ray.d.x) F(ray.d.y) F(ray.d.z) F(idx) F(idy) F(idz) F(clx) F(cly) F(clz) \
-    F(chx) F(chy) F(chz) F(tbest) F(tbest_f) F(kbest) F(ibest) F(cur) F(pend_i) F(sp) F(st)
-__device__ __forceinline__ XRay xray_pick(bool first, const XRay& a, const XRay& b) {
-    XRay w;
-#define ZR_X_PICK(M) w.M = first ? a.M : b.M;
-    ZR_X_EACH(ZR_X_PICK)
-#undef ZR_X_PICK
-    return w;
-}
-__device__ __forceinline__ void xray_put(bool first, const XRay& w, XRay& a, XRay& b) {
-#define ZR_X_PUT(M) a.M = first ? w.M : a.M; b.M = first ? b.M : w.M;
-    ZR_X_EACH(ZR_X_PUT)
-#undef ZR_X_PUT
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(64, 4) void stream_extend_dual(DScene sc, StreamBuf B, SEntry* __restrict__ overflow, unsigned long long* __restrict__ gctr) {
-    __shared__ SEntry lds[2 * ST_LDS_STACK_DUAL * 64];
-    const int lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    SEntry* const gbase = overflow + (size_t)blockIdx.x * 2 * ST_OVERFLOW_DUAL * 64 + lane;
-    const double INF = __builtin_huge_val();
-    const float INFf = __builtin_huge_valf();
-    const uint32_t NONE = 0xFFFFFFFFu;
-    XRay ra, rb;
-    {
-        XRay z;
-        z.slot = 0; z.ray.o = mk(0, 0, 0); z.ray.d = mk(0, 0, 1); z.idx = z.idy = z.idz = 0; z.clx = z.cly = z.clz = z.chx = z.chy = z.chz = 0;
-        z.tbest = INF; z.tbest_f = INFf; z.kbest = NONE; z.ibest = 0; z.cur = 0; z.pend_i = 0; z.sp = 0; z.st = X_IDLE;
-        ra = z; rb = z;
-    }
-    bool work_left = true;
-    uint32_t chunk_next = 0, chunk_end = 0;
-    uint32_t head_shard = blockIdx.x % ST_SHARDS, shards_tried = 0;
-    if (blockIdx.x == 0 && lane < ST_SHARDS) B.ctl[16 + 32 * lane + 16] = 0;  // SHADE of this round recounts the active slots
-    uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_seg = 0, c_hits = 0;
-    unsigned long long s_exec[2] = {0, 0}, s_lanes[2] = {0, 0};
-
-    // the working ray of the current phase; the shared macros (ZR_PUSH, ZR_POP_NEXT, ZR_SLAB, ZR_FBOX, ZR_DESCEND) see it
-    // under the names they use in stream_extend
-    XRay w = ra;
-    uint32_t& slot = w.slot; Ray& ray = w.ray;
-    float &idx_ = w.idx, &idy_ = w.idy, &idz_ = w.idz, &clx = w.clx, &cly = w.cly, &clz = w.clz, &chx = w.chx, &chy = w.chy, &chz = w.chz;
-    double& tbest = w.tbest; float& tbest_f = w.tbest_f;
-    uint32_t &kbest = w.kbest, &ibest = w.ibest, &cur = w.cur, &pend_i = w.pend_i;
-    int &sp = w.sp, &st = w.st;
-    SEntry* lstack = lds;
-    SEntry* gstack = gbase;
-    auto finish = [&]() {
-        B.st(SF_HIT_T, slot, tbest);
-        uint2 ki; ki.x = kbest; ki.y = ibest;
-        B.st2(SF_HIT_KI, slot, ki);
-        if (COUNT && kbest != NONE) c_hits++;
-        st = X_IDLE;
-    };
-#undef ZR_LDS_LEVELS
-#define ZR_LDS_LEVELS ST_LDS_STACK_DUAL
-
-    const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
-    unsigned long long iter = 0;
-    for (; iter < iter_cap; iter++) {
-        const uint32_t ka = (ra.cur >> 28) & 7u, kb = (rb.cur >> 28) & 7u;
-        const bool aN = ra.st == X_NODE, bN = rb.st == X_NODE;
-        const bool aT = ra.st == X_LEAF && ka == ZR_PRIM_TRIANGLE, bT = rb.st == X_LEAF && kb == ZR_PRIM_TRIANGLE;
-        const bool aS = ra.st == X_LEAF && ka == ZR_PRIM_SPHERE, bS = rb.st == X_LEAF && kb == ZR_PRIM_SPHERE;
-        const bool aI = ra.st == X_IDLE, bI = rb.st == X_IDLE;
-        const int n1 = __popcll(__ballot(aN || bN));
-        const int n2t = __popcll(__ballot(aT || bT));
-        const int n2s = __popcll(__ballot(aS || bS));
-        const int n0 = work_left ? __popcll(__ballot(aI || bI)) : 0;
-        const int n2 = n2t > n2s ? n2t : n2s;
-        if (n1 + n2 + n0 == 0) break;
-
-        if (n0 >= ST_FETCH_MIN_DUAL || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
-            // ================= FETCH: every lane with an idle ray takes the next ray index =================
-            const bool mine = aI || bI;
-            const unsigned long long idle = __ballot(mine);
-            uint32_t n = (uint32_t)__popcll(idle);
-            while (chunk_next >= chunk_end && work_left) {
-                uint32_t nb = 0;
-                if (lane == 0) nb = atomicAdd(&B.ctl[16 + 32 * head_shard + 8], 1u);
-                nb = __builtin_amdgcn_readfirstlane(nb);
-                const unsigned long long first = ((unsigned long long)nb * ST_SHARDS + head_shard) * ST_CHUNK;
-                if (first < (unsigned long long)B.P) {
-                    chunk_next = (uint32_t)first;
-                    chunk_end = first + ST_CHUNK < (unsigned long long)B.P ? (uint32_t)first + ST_CHUNK : B.P;
-                } else {
-                    head_shard = (head_shard + 1) % ST_SHARDS;
-                    if (++shards_tried >= ST_SHARDS) work_left = false;
-                }
-            }
-            if (!work_left) n = 0;
-            if (n > chunk_end - chunk_next) n = chunk_end - chunk_next;
-            const uint32_t base = chunk_next;
-            chunk_next += n;
-            const uint32_t lim = base + n;
-            if (mine) {
-                const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
-                if (my < lim) {
-                    const uint2 m = B.ld2(SF_MA, my);
-                    if (m.y & F_ACTIVE) {
-                        const bool first = aI;
-                        lstack = lds + (first ? 0 : ST_LDS_STACK_DUAL * 64);
-                        gstack = gbase + (first ? 0 : ST_OVERFLOW_DUAL * 64);
-                        slot = my;
-                        ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
-                        {
-                            const float NANf = __builtin_nanf("");
-                            idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
-                            float ocx = (float)(-ray.o.x * (double)idx_), ocy = (float)(-ray.o.y * (double)idy_), ocz = (float)(-ray.o.z * (double)idz_);
-                            if (!(fabsf(idx_) < 1.2676506e30f) || !(fabsf(ocx) < 1.3292280e36f)) { idx_ = 0.0f; ocx = NANf; }
-                            if (!(fabsf(idy_) < 1.2676506e30f) || !(fabsf(ocy) < 1.3292280e36f)) { idy_ = 0.0f; ocy = NANf; }
-                            if (!(fabsf(idz_) < 1.2676506e30f) || !(fabsf(ocz) < 1.3292280e36f)) { idz_ = 0.0f; ocz = NANf; }
-                            const float sx = copysignf(fabsf(ocx) * 2.3841858e-7f, idx_), sy = copysignf(fabsf(ocy) * 2.3841858e-7f, idy_), sz = copysignf(fabsf(ocz) * 2.3841858e-7f, idz_);
-                            clx = ocx - sx; chx = ocx + sx; cly = ocy - sy; chy = ocy + sy; clz = ocz - sz; chz = ocz + sz;
-                        }
-                        tbest = INF; tbest_f = INFf; kbest = NONE; ibest = 0; cur = 0; sp = 0; pend_i = 0; st = X_IDLE;
-                        if (COUNT) c_seg++;
-                        float tn0, tn1, tn2, tn3;
-                        uint32_t r0, r1, r2, r3;
-                        ZR_FBOX(sc.root, 0, tn0, r0)
-                        ZR_FBOX(sc.root, 1, tn1, r1)
-                        ZR_FBOX(sc.root, 2, tn2, r2)
-                        ZR_FBOX(sc.root, 3, tn3, r3)
-                        ZR_DESCEND()
-                        xray_put(first, w, ra, rb);
-                    }
-                }
-            }
-        } else if (n1 >= n2) {
-            // ================= NODE: one 4-wide node for one ray of every lane that has one waiting =================
-            if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
-            if (aN || bN) {
-                const bool first = aN;
-                w = xray_pick(first, ra, rb);
-                lstack = lds + (first ? 0 : ST_LDS_STACK_DUAL * 64);
-                gstack = gbase + (first ? 0 : ST_OVERFLOW_DUAL * 64);
-                float tn0, tn1, tn2, tn3;
-                uint32_t r0, r1, r2, r3;
-                const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
-                const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
-                const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
-                const float blx = fmaf(ax_, -3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, clx)), bhx = fmaf(ax_, 3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, chx));
-                const float bly = fmaf(ay_, -3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, cly)), bhy = fmaf(ay_, 3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, chy));
-                const float blz = fmaf(az_, -3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, clz)), bhz = fmaf(az_, 3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, chz));
-#define ZR_QBOX(C, RF_IN, TN, RF)                                                                                          \
-    ZR_SLAB(fmaf((float)((w1.z >> (8 * C)) & 0xFFu), ax_, blx), fmaf((float)((w2.y >> (8 * C)) & 0xFFu), ax_, bhx),         \
-            fmaf((float)((w1.w >> (8 * C)) & 0xFFu), ay_, bly), fmaf((float)((w2.z >> (8 * C)) & 0xFFu), ay_, bhy),         \
-            fmaf((float)((w2.x >> (8 * C)) & 0xFFu), az_, blz), fmaf((float)((w2.w >> (8 * C)) & 0xFFu), az_, bhz), RF_IN, TN, RF)
-                ZR_QBOX(0, ref.x, tn0, r0)
-                ZR_QBOX(1, ref.y, tn1, r1)
-                ZR_QBOX(2, ref.z, tn2, r2)
-                ZR_QBOX(3, ref.w, tn3, r3)
-#undef ZR_QBOX
-                ZR_DESCEND()
-                xray_put(first, w, ra, rb);
-            }
-        } else {
-            // ================= LEAF: one primitive of the kind with most waiting lanes =================
-            if (COUNT) { s_exec[1]++; s_lanes[1] += n2; }
-            const bool do_tri = n2t == n2;
-            const bool mine = do_tri ? (aT || bT) : (aS || bS);
-            if (mine) {
-                const bool first = do_tri ? aT : aS;
-                w = xray_pick(first, ra, rb);
-                lstack = lds + (first ? 0 : ST_LDS_STACK_DUAL * 64);
-                gstack = gbase + (first ? 0 : ST_OVERFLOW_DUAL * 64);
-                const uint32_t prim = (cur & 0xFFFFFFu) + pend_i;
-                double t;
-                if (do_tri) {
-                    if (COUNT) c_tri++;
-                    if (triangle_t(sc.tri_v + (size_t)prim * 9, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = ZR_PRIM_TRIANGLE; ibest = prim; }
-                } else {
-                    if (COUNT) c_sph++;
-                    if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = ZR_PRIM_SPHERE; ibest = prim; }
-                }
-                pend_i++;
-                if (pend_i > ((cur >> 24) & 0xFu)) { ZR_POP_NEXT() }
-                xray_put(first, w, ra, rb);
-            }
-        }
-    }
-#undef ZR_LDS_LEVELS
-#define ZR_LDS_LEVELS ST_LDS_STACK
-    if (iter >= iter_cap && lane == 0) atomicAdd(&B.ctl[2], 1u);
-    if (COUNT) {
-        atomicAdd(&gctr[1], (unsigned long long)c_seg);
-        atomicAdd(&gctr[2], (unsigned long long)c_nodes);
-        atomicAdd(&gctr[3], (unsigned long long)c_sph);
-        atomicAdd(&gctr[4], (unsigned long long)c_tri);
-        atomicAdd(&gctr[7], (unsigned long long)c_hits);
-        if (lane == 0) for (int k = 0; k < 2; k++) { atomicAdd(&gctr[9 + 2 * k], s_exec[k]); atomicAdd(&gctr[10 + 2 * k], s_lanes[k]); }
-    }
-}
-
 // ---- SHADE: one segment of every active slot ------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
@@ -809,7 +589,7 @@ __global__ __launch_bounds__(256) void stream_hits_out(DScene sc, StreamBuf B, u
 
 // ---- host-side launch helpers -----------------------------------------------------------------------------------
 size_t stream_ctl_words() { return 16 + 32 * ST_SHARDS; }
-size_t stream_overflow_bytes(int blocks) { return (size_t)blocks * 2 * ZR_STACK_DEPTH * 64 * sizeof(SEntry); }
+size_t stream_overflow_bytes(int blocks) { return (size_t)blocks * ST_OVERFLOW * 64 * sizeof(SEntry); }
 
 int stream_extend_blocks() {
     int dev = 0, cus = 256, per_cu = 16;
@@ -834,26 +614,10 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
     return B;
 }
 
-static int g_extend_dual = -1;  // ZR_EXTEND_DUAL: two rays per lane for worlds of bare triangles and spheres
-static bool extend_dual() {
-    if (g_extend_dual < 0) { const char* v = std::getenv("ZR_EXTEND_DUAL"); g_extend_dual = v && *v ? std::atoi(v) != 0 : ZR_EXTEND_DUAL_DEFAULT; }
-    return g_extend_dual != 0;
-}
 template <bool COUNT>
 static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, int blocks, unsigned long long* gctr, bool generic, hipStream_t st) {
     if (generic) hipLaunchKernelGGL((stream_extend<COUNT, true>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
-    else if (extend_dual()) {
-        // half as many waves carry the same number of rays; never more than the kernel's own residency
-        static int dual_blocks = 0;
-        if (!dual_blocks) {
-            int dev = 0, cus = 256, per_cu = 0;
-            if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; }
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend_dual<false>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-            dual_blocks = cus * per_cu;
-        }
-        const int eb = blocks < dual_blocks ? blocks : dual_blocks;
-        hipLaunchKernelGGL((stream_extend_dual<COUNT>), dim3(eb), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
-    } else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
+    else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
 }
 
 // The slot pool can be split into K sub-pools that run a fraction of a round apart on K HIP streams, so that one
