@@ -40,6 +40,10 @@ namespace zr {
 #ifndef ST_FETCH_MIN
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
+#ifndef ST_BIAS_NODE
+#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF; favouring LEAF 2:1 is 3 % faster on cfg3 (a tested leaf shrinks tbest and culls the stack), 1:1 and 3:1 are slower */
+#define ST_BIAS_LEAF 2
+#endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
 #define ST_LDS_STACK 12
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
                     }
                 }
             }
-        } else if (n1 >= n2) {
+        } else if (n1 * ST_BIAS_NODE >= n2 * ST_BIAS_LEAF) {
             // ================= NODE: one 4-wide node per lane =================
             if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
 #ifdef ZR_WAVE_PROFILE
