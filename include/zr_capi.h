@@ -271,6 +271,14 @@ int zr_render_aov(zr_ctx*, const zr_scene*, const zr_camera*, uint64_t seed, con
 int zr_render_passes(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed, const zr_region* region,
                      double* out_beauty, double* out_reflection, double* out_refraction);
 
+/* Known answers for whole paths: walks the primary sample (px, py, sample) of each request on the device and records
+ * every segment, ZR_PATH_RECORD doubles each: ray origin, direction | hit flag, t, material id | scattered flag,
+ * attenuation rgb | emission rgb | main-stream RNG draws consumed so far.  requests = n * 3 ints; out = n * max_segments *
+ * ZR_PATH_RECORD doubles (zero-filled past the path's end).  Same arithmetic as zr_render; the environment plays no role
+ * (a miss ends the record list). */
+#define ZR_PATH_RECORD 17
+int zr_trace_paths(zr_ctx*, const zr_scene*, const zr_camera*, uint64_t seed, const int32_t* requests, int n, int max_segments, double* out);
+
 /* counters + device time of the last render on this context (synchronises the context's stream) */
 int zr_get_counters(zr_ctx*, zr_counters*);
 /* drains the log of render-kernel launch durations (ms, measured with HIP events on the launch stream) recorded

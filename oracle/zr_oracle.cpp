@@ -870,6 +870,49 @@ int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t
     return ZR_OK;
 }
 
+// per-segment records of primary samples, the layout of zr_trace_paths (include/zr_capi.h)
+int zro_trace_paths(void* scene, const zr_camera* cam_in, uint64_t seed, const int32_t* req, int n, int max_seg, double* out) {
+    const Scene& sc = *(Scene*)scene;
+    Cam cam; cam.c = *cam_in; cam.initialize();
+    const int W = cam.c.image_width, R = 17;
+    for (int q = 0; q < n; q++) {
+        double* rec_out = out + (size_t)q * max_seg * R;
+        for (int k = 0; k < max_seg * R; k++) rec_out[k] = 0.0;
+        const int px = req[q * 3], py = req[q * 3 + 1], smp = req[q * 3 + 2];
+        Rng g; g.key = zr_stream_key(seed, (uint64_t)py * W + px, (uint64_t)smp);
+        Ray cur = cam.get_ray(px, py, g);
+        V3 beta(1, 1, 1);
+        int inner = -1;
+        for (int seg = 0; seg < max_seg && seg < cam.c.max_depth; seg++) {
+            double* o = rec_out + (size_t)seg * R;
+            for (int k = 0; k < 3; k++) { o[k] = cur.o[k]; o[3 + k] = cur.d[k]; }
+            Rec rec;
+            bool h = sc.world_hit(cur, 0.001, kInf, rec, g, nullptr);
+            g.bounce++;
+            if (!h) { o[6] = 0; o[16] = (double)g.k; break; }
+            V3 em = sc.emitted(rec);
+            V3 att; Ray nxt;
+            bool ok = sc.scatter(cur, rec, att, nxt, g);
+            o[6] = 1; o[7] = rec.t; o[8] = (double)rec.mat; o[9] = ok ? 1 : 0;
+            for (int k = 0; k < 3; k++) { o[10 + k] = ok ? att[k] : 0; o[13 + k] = em[k]; }
+            if (!ok) { o[16] = (double)g.k; break; }
+            beta = beta * att;
+            cur = nxt;
+            if (inner > 10) {
+                if (len(beta) < 0.0001) { o[16] = (double)g.k; break; }
+                double p = std::max({beta.x(), beta.y(), beta.z()});
+                p = clampd(p, 0.05, 0.95);
+                if (g.next() > p) { o[16] = (double)g.k; break; }
+                beta = beta * (1 / p);
+            }
+            if (inner < 0) beta = V3(1, 1, 1);
+            inner++;
+            o[16] = (double)g.k;
+        }
+    }
+    return ZR_OK;
+}
+
 // beauty / reflection / refraction with both split flags on (camera.hpp:490-517, 531-533); outputs region-sized h*w*3
 int zro_render_passes(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t seed, const zr_region* region, double* beauty,
                       double* reflection, double* refraction, zr_counters* ctr) {

@@ -40,6 +40,7 @@ def load():
     lib.zro_render_aov.argtypes = [vp, C.POINTER(capi.Camera), C.c_uint64, C.POINTER(capi.Region), C.c_double, vp, vp, vp]
     lib.zro_render_passes.argtypes = [vp, C.POINTER(capi.Camera), C.POINTER(capi.Env), C.c_uint64, C.POINTER(capi.Region), vp, vp, vp,
                                       C.POINTER(capi.Counters)]
+    lib.zro_trace_paths.argtypes = [vp, C.POINTER(capi.Camera), C.c_uint64, vp, C.c_int, C.c_int, vp]
     lib.zro_trace.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     lib.zro_scatter.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     _lib = lib
@@ -76,6 +77,12 @@ class OracleScene:
         self.lib.zro_render_aov(self._s, C.byref(camera), C.c_uint64(seed), C.byref(region), float(zmax), outs[0].ctypes.data,
                                 outs[1].ctypes.data, outs[2].ctypes.data)
         return outs
+
+    def trace_paths(self, camera, seed, requests, max_segments):
+        req = np.ascontiguousarray(requests, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros((req.shape[0], max_segments, 17), dtype=np.float64)
+        self.lib.zro_trace_paths(self._s, C.byref(camera), C.c_uint64(seed), req.ctypes.data, req.shape[0], max_segments, out.ctypes.data)
+        return out
 
     def render_passes(self, camera, env, seed, region):
         """beauty / reflection / refraction tiles (region-sized) + counters"""

@@ -120,7 +120,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
 ]
 
@@ -155,6 +155,7 @@ def load():
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
     lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
+    lib.zr_trace_paths.argtypes = [vp, vp, C.POINTER(Camera), u64, vp, i32, i32, vp]
     lib.zr_render_passes.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), vp, vp, vp]
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.zr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), i32]
@@ -303,6 +304,16 @@ class Scene:
         _check(self.lib.zr_render_aov(self.ctx._c, self._s, C.byref(camera), C.c_uint64(seed), rp, C.byref(ap),
                                       outs[0].ctypes.data, outs[1].ctypes.data, outs[2].ctypes.data))
         return outs
+
+    PATH_RECORD = 17
+
+    def trace_paths(self, camera, seed, requests, max_segments):
+        """per-segment records of the primary samples (px, py, sample): (n, max_segments, 17) float64, see zr_trace_paths"""
+        req = np.ascontiguousarray(requests, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros((req.shape[0], max_segments, self.PATH_RECORD), dtype=np.float64)
+        _check(self.lib.zr_trace_paths(self.ctx._c, self._s, C.byref(camera), C.c_uint64(seed), req.ctypes.data, req.shape[0], max_segments,
+                                       out.ctypes.data))
+        return out
 
     def render_passes(self, camera, env, seed, region=None):
         """beauty / reflection / refraction frames with the split enabled (camera.hpp:490-517): three (H, W, 3) float64 frames"""

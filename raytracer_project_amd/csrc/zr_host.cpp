@@ -1139,6 +1139,28 @@ int zr_render_passes(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const z
     return ZR_OK;
 }
 
+int zr_trace_paths(zr_ctx* c, const zr_scene* s, const zr_camera* cam, uint64_t seed, const int32_t* requests, int n, int max_segments, double* out) {
+    if (!c || !s || !cam || (n > 0 && (!requests || !out))) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_trace_paths");
+    if (n <= 0 || max_segments <= 0) return ZR_OK;
+    static_assert(ZR_PATH_RECORD == ZR_PATH_REC, "record size");
+    HIP_OK(hipSetDevice(c->device));
+    zr::DCamera dc; make_camera(*cam, dc);
+    for (int k = 0; k < n; k++)
+        if (requests[3 * k] < 0 || requests[3 * k] >= dc.W || requests[3 * k + 1] < 0 || requests[3 * k + 1] >= dc.H || requests[3 * k + 2] < 0)
+            return fail(ZR_E_INVALID, "path request %d outside the frame", k);
+    DevBuf<int32_t> d_req; DevBuf<double> d_out;
+    std::vector<int32_t> r(requests, requests + (size_t)n * 3);
+    int rc;
+    if ((rc = d_req.upload(r))) return rc;
+    const size_t words = (size_t)n * max_segments * ZR_PATH_RECORD;
+    if ((rc = d_out.alloc(words))) return rc;
+    HIP_OK(zr::launch_path_records(s->ds, dc, seed, d_req.p, n, max_segments, d_out.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out, d_out.p, words * sizeof(double), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
 int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (!c || !out) return fail(ZR_E_INVALID, "null argument");
     HIP_OK(hipSetDevice(c->device));

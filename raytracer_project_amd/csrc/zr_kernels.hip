@@ -296,6 +296,53 @@ __global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* 
     out[k] = o;
 }
 
+// ---- known-answer kernel for whole paths: one thread walks one primary sample and records every segment ------------
+// record (ZR_PATH_REC doubles per segment): ray o, d | hit flag, t, material | scattered flag, attenuation rgb |
+// emission rgb | main-stream draws consumed after this segment
+__global__ __launch_bounds__(ZR_BLOCK) void path_records(DScene sc, DCamera cam, uint64_t seed, const int32_t* __restrict__ req, int n_req, int max_seg,
+                                                          double* __restrict__ out) {
+    __shared__ uint32_t lds_stack[ZR_STACK_DEPTH * ZR_BLOCK];
+    const int q = blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (q >= n_req) return;
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const int px = req[q * 3], py = req[q * 3 + 1], smp = req[q * 3 + 2];
+    double* rec_out = out + (size_t)q * max_seg * ZR_PATH_REC;
+    for (int k = 0; k < max_seg * ZR_PATH_REC; k++) rec_out[k] = 0.0;
+    Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)smp); g.k = 0; g.bounce = 0;
+    Counters ctr = {0, 0, 0, 0, 0};
+    Ray cur = camera_ray(cam, px, py, g);
+    V3 beta = mk(1, 1, 1);
+    int inner = -1;  // -1: the peeled first bounce (ray_color_from_hit), then ray_color's loop index
+    for (int seg = 0; seg < max_seg && seg < cam.max_depth; seg++) {
+        double* o = rec_out + (size_t)seg * ZR_PATH_REC;
+        o[0] = cur.o.x; o[1] = cur.o.y; o[2] = cur.o.z; o[3] = cur.d.x; o[4] = cur.d.y; o[5] = cur.d.z;
+        double t; uint32_t kind, idx;
+        bool h = closest_hit<false>(sc, cur, 0.001, g, stack, ZR_BLOCK, t, kind, idx, ctr);
+        g.bounce++;
+        if (!h) { o[6] = 0; o[16] = (double)g.k; break; }
+        Rec rec;
+        object_rec(sc, kind, idx, cur, t, rec);
+        V3 em = emitted(sc, rec);
+        V3 att; Ray nxt;
+        bool ok = scatter(sc, cur, rec, att, nxt, g);
+        o[6] = 1; o[7] = t; o[8] = (double)rec.mat; o[9] = ok ? 1 : 0;
+        o[10] = ok ? att.x : 0; o[11] = ok ? att.y : 0; o[12] = ok ? att.z : 0; o[13] = em.x; o[14] = em.y; o[15] = em.z;
+        if (!ok) { o[16] = (double)g.k; break; }
+        beta = beta * att;
+        cur = nxt;
+        if (inner > 10) {   // camera.hpp:972-980, loop index of ray_color
+            if (len(beta) < 0.0001) { o[16] = (double)g.k; break; }
+            double p = fmax(fmax(beta.x, beta.y), beta.z);
+            p = clampd(p, 0.05, 0.95);
+            if (g.next() > p) { o[16] = (double)g.k; break; }
+            beta = beta * (1 / p);
+        }
+        if (inner < 0) beta = mk(1, 1, 1);   // ray_color starts its own beta after the peeled bounce
+        inner++;
+        o[16] = (double)g.k;
+    }
+}
+
 // ---- launch wrappers (called from zr_host.cpp) -------------------------------------------------------
 hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
                          unsigned long long* gctr, bool count, hipStream_t stream) {
@@ -330,6 +377,13 @@ hipError_t launch_passes(const DScene& sc, const DCamera& cam, const DEnv& env, 
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(passes_pixels, dim3((unsigned)blocks), dim3(ZR_BLOCK), 0, stream, sc, cam, env, seed, wd, out_beauty, out_reflection, out_refraction, gctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_path_records(const DScene& sc, const DCamera& cam, uint64_t seed, const int32_t* req, int n_req, int max_seg, double* out,
+                               hipStream_t stream) {
+    if (n_req <= 0) return hipSuccess;
+    hipLaunchKernelGGL(path_records, dim3((unsigned)((n_req + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, sc, cam, seed, req, n_req, max_seg, out);
     return hipGetLastError();
 }
 

@@ -51,6 +51,9 @@ hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const
                       double* out_albedo, double* out_normal, double* out_zdepth, hipStream_t stream);
 hipError_t launch_passes(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out_beauty,
                          double* out_reflection, double* out_refraction, unsigned long long* gctr, hipStream_t stream);
+#define ZR_PATH_REC 17
+hipError_t launch_path_records(const DScene& sc, const DCamera& cam, uint64_t seed, const int32_t* req, int n_req, int max_seg, double* out,
+                               hipStream_t stream);
 hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
                         uint32_t bounce, zr_hit* out, hipStream_t stream);
 

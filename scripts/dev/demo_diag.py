@@ -1,0 +1,23 @@
+"""Development aid (GPU): where does a scene differ from the oracle?  Bisects over max_depth and spp."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from raytracer_project_amd import capi
+from oracle import zr_oracle_py as zo
+ctx = capi.Context(0)
+ds = capi.DemoScene("demo"); sc = capi.Scene(ctx, ds.desc); osc = zo.OracleScene(ds.desc)
+x0, y0, w, h = 560, 300, 48, 32
+reg = capi.Region(x0, y0, w, h, 0, 0, 0, 0)
+for depth in (1, 2, 3, 4, 10):
+    cam = ds.camera.copy(); cam.samples_per_pixel = 32; cam.max_depth = depth
+    g = sc.render(cam, ds.env, ds.seed, reg, count=True); gc = ctx.counters()
+    o, oc, _, _ = osc.render(cam, ds.env, ds.seed, reg)
+    gt, ot = g[y0:y0+h, x0:x0+w], o[y0:y0+h, x0:x0+w]
+    err = np.abs(gt - ot) / np.maximum(np.abs(ot), 1e-9)
+    bad = np.argwhere(err.max(axis=2) > 1e-4)
+    print("max_depth", depth, "bad pixels", len(bad), "segments", gc.segments, oc.segments, "draws", gc.rng_draws, oc.rng_draws, [(int(y) + y0, int(x) + x0) for y, x in bad[:6]])
+# first-hit AOV of the bad pixels: which material / normal is there
+cam = ds.camera.copy(); cam.samples_per_pixel = 32
+a, n, z = sc.render_aov(cam, ds.seed, 30.0, reg)
+for y, x in bad[:8]:
+    print((int(y) + y0, int(x) + x0), "albedo", a[y + y0, x + x0], "normal", n[y + y0, x + x0], "z", z[y + y0, x + x0, 0])

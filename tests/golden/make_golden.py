@@ -36,6 +36,9 @@ TILES = {
     "mix2_full": ("mix2", 0, 0, 96, 64, 0, False, []),
     "mix0_tile": ("mix0", 30, 20, 16, 16, 0, True, []),
     "mesh0_full": ("mesh0", 0, 0, 96, 64, 0, False, []),            # OBJ ingest through `model`
+    # the reference's own demo workload (scene_management.hpp:103-236): 900 instanced prefabs, a wrapped mesh, fog
+    "demo_tile": ("demo", 560, 300, 48, 32, 32, False, []),          # mesh + mirror sphere + glass cube
+    "demo_tile_b": ("demo", 200, 420, 40, 24, 32, True, []),         # the instance grid through the fog
 }
 TRACES = {
     # name -> (scene, rays, seed, probe-box clamp lo, hi, extra scene args)
@@ -44,6 +47,7 @@ TRACES = {
     "trace_cfg5": ("cfg5", 2048, 13, -30, 600, []),
     "trace_cfg3_small": ("cfg3", 2048, 14, -4, 4, [200, 20, 256, 128]),
     "trace_mesh0": ("mesh0", 4096, 15, -3, 4, []),
+    "trace_demo": ("demo", 4096, 16, -16, 16, []),
     # adversarial rays (ZR_TRACE_ADVERSARIAL: zero direction components, tiny/large scales, round and far origins)
     "trace_adv_mix0": ("mix0", 4096, 21, -6, 6, [], True),
     "trace_adv_cfg2": ("cfg2", 4096, 22, -12, 12, [], True),

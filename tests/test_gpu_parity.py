@@ -18,7 +18,7 @@ REL_TOL = 1e-4      # north_star: "within 1e-4 relative per-channel"
 ABS_FLOOR = 1e-7    # radiance below this is treated as 0 for the relative comparison
 
 TILE_FIXTURES = ["cfg1_full", "cfg1_tile", "cfg2_tile", "cfg2_tile_b", "cfg3_small", "cfg3_full", "cfg5_tile",
-                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full"]
+                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "demo_tile", "demo_tile_b"]
 
 
 @pytest.fixture(scope="module")
@@ -75,7 +75,7 @@ def test_radiance_matches_reference(name, ctx):
 
 
 @pytest.mark.parametrize("engine", ["extend", "pairs"])
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0",
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_demo",
                                   "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records, through both
@@ -305,6 +305,32 @@ def test_reflection_refraction_passes_match_reference(name, ctx):
     assert not b[outside].any() and not r[outside].any() and not f[outside].any()
     plain = sc.render(cam, ds.env, ds.seed, reg)
     _check(b[sl], plain[sl], name + " beauty vs zr_render")
+
+
+@pytest.mark.parametrize("name", ["mix0", "mix1", "mix2", "cfg2", "cfg5", "mesh0", "demo"])
+def test_path_records_match_oracle(name, ctx):
+    """zr_trace_paths: every segment of 3000 primary samples — ray, hit, material, scatter decision, attenuation, emission
+    and the number of RNG draws consumed — against the CPU oracle walking the same samples.  This is the device-side
+    known-answer test of material::scatter / emitted and of the integrator's bookkeeping, segment by segment."""
+    from oracle import zr_oracle_py as zo
+    ds = demo_scene(name)
+    cam = ds.camera.copy()
+    sc = gpu_scene(ctx, name)
+    rng = np.random.default_rng(11)
+    n = 3000
+    req = np.stack([rng.integers(0, cam.image_width, n), rng.integers(0, cam.image_height, n), rng.integers(0, cam.samples_per_pixel, n)], axis=1)
+    nseg = min(cam.max_depth, 24)
+    g = sc.trace_paths(cam, ds.seed, req, nseg)
+    o = zo.OracleScene(ds.desc).trace_paths(cam, ds.seed, req, nseg)
+    # decisions and counts are exact: hit flag, material, scattered flag, draws
+    for col, what in ((6, "hit flag"), (8, "material"), (9, "scatter decision"), (16, "RNG draws")):
+        bad = np.argwhere(g[:, :, col] != o[:, :, col])
+        assert len(bad) == 0, f"{what}: {len(bad)} segments differ, first at request {req[bad[0][0]]} segment {bad[0][1]}"
+    tol = 1e-7   # last-bit differences (fused multiply-add, libm) grow along a path of up to 24 refractions; decisions stay exact
+    for cols, what in ((slice(0, 6), "ray"), (slice(7, 8), "t"), (slice(10, 13), "attenuation"), (slice(13, 16), "emission")):
+        err = np.abs(g[:, :, cols] - o[:, :, cols]) / np.maximum(1.0, np.abs(o[:, :, cols]))
+        assert err.max() < tol, f"{what}: max error {err.max():.3e}"
+    assert (o[:, :, 6] > 0).sum() > n, "the requests barely hit anything"
 
 
 def test_cxx_host_collective_single_rank(ctx):
