@@ -863,13 +863,56 @@ struct EnvironmentSettings {
     double sun_size = 1.0;
 };
 
-// the fields of post_processor that camera::render reads (camera.hpp:247,259,280); the post stack itself
-// is out of scope
+// post_processor (color_processing.hpp:44-75): the reference's public fields and defaults.  The arithmetic (process, bloom,
+// sharpening, analyze_framebuffer) runs on the device: camera::process_framebuffer / camera::analyze below.
+struct debug_flags {
+    bool red = false, green = false, blue = false, luminance = false, bvh = false;
+    bool any_active() const { return red || green || blue || luminance || bvh; }
+};
+struct image_statistics {
+    float average_luminance = 0.0f, max_luminance = 0.0f;
+    int histogram[256] = {0};
+    float normalized_histogram[256] = {0.0f};
+    void normalize() {  // color_processing.hpp:15-27
+        int max_pixels = 0;
+        for (int i = 0; i < 256; i++) if (histogram[i] > max_pixels) max_pixels = histogram[i];
+        if (max_pixels > 0) for (int i = 0; i < 256; i++) normalized_histogram[i] = static_cast<float>(histogram[i]) / max_pixels;
+    }
+};
 struct post_processor {
-    double z_depth_max_dist = 20.0;
-    bool use_auto_exposure = false;
+    mutable float exposure = 0.5f;
+    float saturation = 1.0f, contrast = 1.0f, hue_shift = 0.0f, vignette_intensity = 1.0f;
+    vec3 color_balance = vec3(1.0f, 1.0f, 1.0f);
+    float z_depth_max_dist = 1.0f;
+    float exposure_compensation_stops = 0.0f;
+    bool use_aces_tone_mapping = false, use_auto_exposure = false;
+    float target_luminance = 0.12f;
+    mutable debug_flags debug;
+    bool use_bloom = false;
+    float bloom_threshold = 1.0f, bloom_intensity = 0.3f;
+    int bloom_radius = 4;
+    bool needs_update = true;
+    mutable image_statistics last_stats;
     bool use_sharpening = false;
-    mutable float exposure = 1.0f;
+    double sharpen_amount = 0.2;
+
+    double apply_auto_exposure(const image_statistics& stats) const {  // color_processing.hpp:186-205 (scalar, host)
+        if (stats.average_luminance <= 0.0) return static_cast<double>(exposure);
+        if (!use_auto_exposure) return std::clamp(static_cast<float>(exposure), 0.01f, 10.0f);
+        double safe_luminance = std::max(static_cast<double>(stats.average_luminance), 0.02);
+        double raw_exposure = target_luminance / safe_luminance;
+        double current_exp = raw_exposure * std::pow(2.0, static_cast<double>(exposure_compensation_stops));
+        return std::clamp(static_cast<float>(current_exp), 0.01f, 4.0f);
+    }
+    zr_post_params to_zr() const {
+        zr_post_params p{};
+        p.exposure = exposure; p.saturation = saturation; p.contrast = contrast; p.hue_shift = hue_shift; p.vignette_intensity = vignette_intensity;
+        p.bloom_threshold = bloom_threshold; p.bloom_intensity = bloom_intensity; p.bloom_radius = bloom_radius;
+        for (int k = 0; k < 3; k++) p.color_balance[k] = color_balance[k];
+        p.sharpen_amount = sharpen_amount; p.use_aces_tone_mapping = use_aces_tone_mapping; p.use_bloom = use_bloom; p.use_sharpening = use_sharpening;
+        p.debug_red = debug.red; p.debug_green = debug.green; p.debug_blue = debug.blue; p.debug_luminance = debug.luminance; p.debug_bvh = debug.bvh;
+        return p;
+    }
 };
 
 namespace zenith {
@@ -924,7 +967,33 @@ public:
         current_samples_count = 0; lines_rendered = 0;
     }
 
-    // camera.hpp:236.  Blocking; fills render_accumulator (mean radiance, row-major, idx = j*W + i).
+    // camera::process_framebuffer_to_image up to the PNG encoder (camera.hpp:701-780): bloom, sharpening, exposure,
+    // post_processor::process, 8-bit RGB — on the device, byte-exact with the reference.  Data passes (albedo, normals, z-depth,
+    // reflection, refraction) are clamped and gamma-corrected only, as save_render_pass asks (camera.hpp:314-345).
+    bool process_framebuffer(const std::vector<color>& buffer, const post_processor& pp, std::vector<unsigned char>& rgb8,
+                             bool is_data_pass = false, bool apply_gamma = true) const {
+        rgb8.assign((size_t)image_width * image_height * 3, 0);
+        zr_ctx* ctx = zenith::thread_context(device);
+        if (!ctx || buffer.size() != (size_t)image_width * image_height) { std::cerr << "[zenith] process_framebuffer: " << (ctx ? "buffer size mismatch" : zr_last_error()) << "\n"; return false; }
+        zr_post_params p = pp.to_zr();
+        int rc = zr_post_process(ctx, &p, reinterpret_cast<const double*>(buffer.data()), image_width, image_height, is_data_pass, apply_gamma, rgb8.data());
+        if (rc != ZR_OK) std::cerr << "[zenith] process_framebuffer failed: " << zr_last_error() << "\n";
+        return rc == ZR_OK;
+    }
+    // post_processor::analyze_framebuffer (color_processing.hpp:150-183) on the device
+    image_statistics analyze(const std::vector<color>& buffer) const {
+        image_statistics st;
+        zr_ctx* ctx = zenith::thread_context(device);
+        zr_image_stats z{};
+        if (ctx && !buffer.empty() && zr_analyze_frame(ctx, reinterpret_cast<const double*>(buffer.data()), buffer.size(), &z) == ZR_OK) {
+            st.average_luminance = z.average_luminance; st.max_luminance = z.max_luminance;
+            for (int i = 0; i < 256; i++) st.histogram[i] = z.histogram[i];
+            st.normalize();
+        }
+        return st;
+    }
+
+    // camera.hpp:236.  Blocking; fills render_accumulator (mean radiance, row-major, idx = j*W + i)."
     void render(const hittable& world, const EnvironmentSettings& env, const post_processor& post, std::atomic<bool>& render_flag) {
         static_assert(sizeof(std::atomic<bool>) == 1 && sizeof(std::atomic<int>) == sizeof(int), "flag layout");
         if (image_width < 1) image_width = 1;
@@ -971,6 +1040,11 @@ public:
             }
         }
         if (rc != ZR_OK && rc != ZR_E_CANCELLED) std::cerr << "[zenith] render failed: " << zr_last_error() << "\n";
+        if (rc == ZR_OK && post.use_auto_exposure) {   // camera.hpp:258-266
+            image_statistics stats = analyze(render_accumulator);
+            post.last_stats = stats;
+            post.exposure = static_cast<float>(post.apply_auto_exposure(stats));
+        }
         if (sc) zr_scene_destroy(sc);
     }
 };

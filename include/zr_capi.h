@@ -271,6 +271,32 @@ int zr_render_aov(zr_ctx*, const zr_scene*, const zr_camera*, uint64_t seed, con
 int zr_render_passes(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed, const zr_region* region,
                      double* out_beauty, double* out_reflection, double* out_refraction);
 
+/* ---- after the sample loop -------------------------------------------------------------------
+ * zr_post_process = camera::process_framebuffer_to_image up to the PNG encoder (camera.hpp:701-780): optional bloom
+ * (bloom.hpp:18-68 on the 2^exposure-scaled frame), optional sharpening (color_processing.hpp:207-227), then per pixel
+ * x 2^exposure, post_processor::process (color_processing.hpp:76-147: x exposure, colour balance, contrast about 0.18,
+ * vignette, hue/saturation in HSV, ACES, debug views, clamp, gamma 1/2.2) and (unsigned char)(255.999 c).  A data pass
+ * (albedo, normals, z-depth, reflection, refraction frames) is only clamped and, if apply_gamma, gamma-corrected.
+ * frame_rgb: W*H*3 doubles (host); out_rgb8: W*H*3 bytes (host).  Byte-exact with the reference. */
+typedef struct zr_post_params {      /* post_processor, color_processing.hpp:46-75 */
+    float exposure, saturation, contrast, hue_shift, vignette_intensity;
+    float bloom_threshold, bloom_intensity;
+    int32_t bloom_radius;
+    double color_balance[3];
+    double sharpen_amount;
+    int32_t use_aces_tone_mapping, use_bloom, use_sharpening;
+    int32_t debug_red, debug_green, debug_blue, debug_luminance, debug_bvh;
+} zr_post_params;
+int zr_post_process(zr_ctx*, const zr_post_params*, const double* frame_rgb, int width, int height, int is_data_pass, int apply_gamma,
+                    uint8_t* out_rgb8);
+/* post_processor::analyze_framebuffer (color_processing.hpp:150-183): maximum luminance, log2-mean luminance and the
+ * 256-bin log-luminance histogram that auto-exposure (apply_auto_exposure, 186-205) and the GUI plot read */
+typedef struct zr_image_stats {
+    float average_luminance, max_luminance;
+    int32_t histogram[256];
+} zr_image_stats;
+int zr_analyze_frame(zr_ctx*, const double* frame_rgb, size_t n_pixels, zr_image_stats* out);
+
 /* Known answers for whole paths: walks the primary sample (px, py, sample) of each request on the device and records
  * every segment, ZR_PATH_RECORD doubles each: ray origin, direction | hit flag, t, material id | scattered flag,
  * attenuation rgb | emission rgb | main-stream RNG draws consumed so far.  requests = n * 3 ints; out = n * max_segments *

@@ -46,6 +46,8 @@
 #include "bvh.hpp"
 #include "model.hpp"
 #include "environment.hpp"
+#include "bloom.hpp"             // genuine post stack
+#include "color_processing.hpp"
 
 // ---- hooks for scenes/zr_scenes.inc ------------------------------------------------------------
 static void zr_hook_seed_scene(uint64_t seed, uint64_t stream) { zr_oracle_seed(seed, ZR_SCENE_PIXEL, stream); }
@@ -379,6 +381,7 @@ static int usage() {
                  "  zenith_ref trace  <scene> <nrays> <seed> <out_prefix> <clamp_lo> <clamp_hi> [a0 a1 a2 a3]\n"
                  "  zenith_ref aov    <scene> <x0> <y0> <w> <h> <zmax> <out_prefix> - [a0 a1 a2 a3]\n"
                  "  zenith_ref passes <scene> <x0> <y0> <w> <h> <spp|0> <out_prefix> [a0 a1 a2 a3]\n"
+                 "  zenith_ref post   <scene> <preset 0-7> <out_prefix> [spp]\n"
                  "  zenith_ref texels <w> <h> <out.npy>\n");
     return 2;
 }
@@ -488,6 +491,92 @@ int main(int argc, char** argv) {
         std::printf("{\"scene\": \"%s\", \"x0\": %d, \"y0\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"seed\": %llu, \"segments\": %llu, \"draws\": %llu}\n",
                     argv[2], x0, y0, w, h, spp, (unsigned long long)b.s.seed, (unsigned long long)seg_tls.segments,
                     (unsigned long long)zr_oracle_tls.draws);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "post" && argc >= 5) {
+        // zenith_ref post <scene> <preset> <out_prefix> [spp]: renders the scene's full frame (the input of the post stack),
+        // then runs the GENUINE post_processor / bloom_filter through the loop of camera::process_framebuffer_to_image
+        // (camera.hpp:701-780, restated: camera.hpp is unbuildable here) and post_processor::analyze_framebuffer.
+        built_scene b;
+        if (!build(b, argv[2], 0, 0, 0, 0)) return usage();
+        const int preset = iarg(3, 0);
+        std::string out = argv[4];
+        const int spp = iarg(5, 4);
+        ref_camera cam; cam.c = b.s.cam;
+        const int W = cam.c.image_width, H = cam.c.image_height;
+        std::vector<double> mean;
+        render_tile(b, cam, 0, 0, W, H, spp, (int)std::thread::hardware_concurrency(), 1, 1, mean, nullptr, nullptr);
+        std::vector<color> buffer((size_t)W * H);
+        for (size_t i = 0; i < buffer.size(); i++) buffer[i] = color(mean[3 * i], mean[3 * i + 1], mean[3 * i + 2]);
+        post_processor pp;
+        bool is_data_pass = false, apply_gamma = true;
+        switch (preset) {   // parameter sets that reach every branch of process()
+            case 0: break;                                                     // defaults: exposure 0.5, vignette 1
+            case 1: pp.exposure = 1.25f; pp.use_bloom = true; pp.bloom_threshold = 0.8f; pp.bloom_intensity = 0.45f; pp.bloom_radius = 6;
+                    pp.use_aces_tone_mapping = true; break;
+            case 2: pp.exposure = 0.2f; pp.use_sharpening = true; pp.sharpen_amount = 0.25; pp.contrast = 1.3f; pp.saturation = 1.4f;
+                    pp.hue_shift = 35.0f; pp.color_balance = vec3(1.1f, 0.95f, 0.9f); pp.vignette_intensity = 0.6f; break;
+            case 3: pp.exposure = 0.8f; pp.use_bloom = true; pp.use_sharpening = true; pp.saturation = 0.3f; pp.hue_shift = -120.0f;
+                    pp.use_aces_tone_mapping = true; pp.vignette_intensity = 0.0f; pp.contrast = 0.8f; break;
+            case 4: pp.debug.luminance = true; pp.exposure = 0.0f; break;
+            case 5: pp.debug.red = true; pp.debug.blue = true; break;
+            case 6: is_data_pass = true; break;                                // data pass: clamp + gamma
+            case 7: is_data_pass = true; apply_gamma = false; break;
+            default: return usage();
+        }
+        // camera.hpp:707-733
+        std::vector<color> bloom_buffer = buffer;
+        double ev_multiplier = std::pow(2.0, (double)pp.exposure);
+        if (!is_data_pass && pp.use_bloom) {
+            for (auto& pix : bloom_buffer) pix *= ev_multiplier;
+            std::vector<color> bloom_overlay(bloom_buffer.size(), color(0.0, 0.0, 0.0));
+            bloom_filter bloom(pp.bloom_threshold, pp.bloom_intensity, pp.bloom_radius);
+            bloom.generate_bloom_overlay(bloom_buffer, bloom_overlay, W, H, 1.0f);
+            double inv_ev = 1.0 / ev_multiplier;
+            for (size_t i = 0; i < bloom_buffer.size(); ++i) bloom_buffer[i] = buffer[i] + (bloom_overlay[i] * inv_ev);
+        } else {
+            bloom_buffer = buffer;
+        }
+        if (!is_data_pass && pp.use_sharpening) pp.apply_sharpening(bloom_buffer, W, H, pp.sharpen_amount);
+        std::vector<unsigned char> image_data((size_t)W * H * 3);
+        for (int j = 0; j < H; j++)
+            for (int i = 0; i < W; i++) {
+                size_t pixel_idx = static_cast<size_t>(j) * W + i;
+                color pix_color = bloom_buffer[pixel_idx];
+                if (!is_data_pass) {
+                    pix_color *= ev_multiplier;
+                    float u = static_cast<float>(i) / (W - 1);
+                    float v = static_cast<float>(j) / (H - 1);
+                    pix_color = pp.process(pix_color, u, v, render_pass::RGB);
+                } else {
+                    pix_color = color(std::clamp(pix_color.x(), 0.0, 1.0), std::clamp(pix_color.y(), 0.0, 1.0), std::clamp(pix_color.z(), 0.0, 1.0));
+                    if (apply_gamma) pix_color = linear_to_gamma(pix_color);
+                }
+                size_t idx = pixel_idx * 3;
+                image_data[idx + 0] = static_cast<unsigned char>(255.999 * pix_color.x());
+                image_data[idx + 1] = static_cast<unsigned char>(255.999 * pix_color.y());
+                image_data[idx + 2] = static_cast<unsigned char>(255.999 * pix_color.z());
+            }
+        image_statistics st = pp.analyze_framebuffer(buffer);
+        double auto_on; { post_processor q = pp; q.use_auto_exposure = true; q.exposure_compensation_stops = 0.5f; auto_on = q.apply_auto_exposure(st); }
+        double auto_off = pp.apply_auto_exposure(st);
+        write_npy(out + "_frame.npy", "<f8", {(size_t)H, (size_t)W, 3}, mean.data(), mean.size() * 8);
+        write_npy(out + "_rgb8.npy", "|u1", {(size_t)H, (size_t)W, 3}, image_data.data(), image_data.size());
+        std::vector<int32_t> hist(st.histogram, st.histogram + 256);
+        write_npy(out + "_hist.npy", "<i4", {256}, hist.data(), hist.size() * 4);
+        std::printf("{\"scene\": \"%s\", \"preset\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"is_data_pass\": %d, \"apply_gamma\": %d, "
+                    "\"exposure\": %.9g, \"saturation\": %.9g, \"contrast\": %.9g, \"hue_shift\": %.9g, \"vignette_intensity\": %.9g, "
+                    "\"bloom_threshold\": %.9g, \"bloom_intensity\": %.9g, \"bloom_radius\": %d, \"color_balance\": [%.17g, %.17g, %.17g], "
+                    "\"sharpen_amount\": %.17g, \"use_aces_tone_mapping\": %d, \"use_bloom\": %d, \"use_sharpening\": %d, "
+                    "\"debug\": [%d, %d, %d, %d, %d], \"average_luminance\": %.9g, \"max_luminance\": %.9g, \"auto_exposure_on\": %.17g, "
+                    "\"auto_exposure_off\": %.17g}\n",
+                    argv[2], preset, W, H, spp, (int)is_data_pass, (int)apply_gamma, pp.exposure, pp.saturation, pp.contrast, pp.hue_shift,
+                    pp.vignette_intensity, pp.bloom_threshold, pp.bloom_intensity, pp.bloom_radius, pp.color_balance.x(), pp.color_balance.y(),
+                    pp.color_balance.z(), pp.sharpen_amount, (int)pp.use_aces_tone_mapping, (int)pp.use_bloom, (int)pp.use_sharpening,
+                    (int)pp.debug.red, (int)pp.debug.green, (int)pp.debug.blue, (int)pp.debug.luminance, (int)pp.debug.bvh,
+                    st.average_luminance, st.max_luminance, auto_on, auto_off);
         cleanup(b);
         return 0;
     }

@@ -41,6 +41,10 @@ def load():
     lib.zro_render_passes.argtypes = [vp, C.POINTER(capi.Camera), C.POINTER(capi.Env), C.c_uint64, C.POINTER(capi.Region), vp, vp, vp,
                                       C.POINTER(capi.Counters)]
     lib.zro_trace_paths.argtypes = [vp, C.POINTER(capi.Camera), C.c_uint64, vp, C.c_int, C.c_int, vp]
+    lib.zro_post_process.argtypes = [C.POINTER(capi.PostParams), vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.zro_analyze_frame.argtypes = [vp, C.c_size_t, C.POINTER(capi.ImageStats)]
+    lib.zro_auto_exposure.restype = C.c_double
+    lib.zro_auto_exposure.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.zro_trace.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     lib.zro_scatter.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     _lib = lib
@@ -116,6 +120,26 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def post_process(params, frame, is_data_pass=False, apply_gamma=True):
+    """CPU restatement of the post stack (zr_post_oracle.cpp)"""
+    frame = np.ascontiguousarray(frame, dtype=np.float64)
+    h, w = frame.shape[:2]
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    load().zro_post_process(C.byref(params), frame.ctypes.data, w, h, int(is_data_pass), int(apply_gamma), out.ctypes.data)
+    return out
+
+
+def analyze_frame(frame):
+    frame = np.ascontiguousarray(frame, dtype=np.float64)
+    st = capi.ImageStats()
+    load().zro_analyze_frame(frame.ctypes.data, frame.size // 3, C.byref(st))
+    return st
+
+
+def auto_exposure(average_luminance, exposure, use_auto_exposure, target_luminance=0.12, compensation_stops=0.0):
+    return load().zro_auto_exposure(average_luminance, exposure, int(use_auto_exposure), target_luminance, compensation_stops)
 
 
 def ref_available():

@@ -67,6 +67,31 @@ class Region(C.Structure):
                 ("tile_mod", C.c_int32), ("tile_rem", C.c_int32), ("pad_", C.c_int32)]
 
 
+class PostParams(C.Structure):
+    """zr_post_params: post_processor's fields (color_processing.hpp:46-75); defaults are the reference's"""
+    _fields_ = [("exposure", C.c_float), ("saturation", C.c_float), ("contrast", C.c_float), ("hue_shift", C.c_float),
+                ("vignette_intensity", C.c_float), ("bloom_threshold", C.c_float), ("bloom_intensity", C.c_float), ("bloom_radius", C.c_int32),
+                ("color_balance", C.c_double * 3), ("sharpen_amount", C.c_double), ("use_aces_tone_mapping", C.c_int32),
+                ("use_bloom", C.c_int32), ("use_sharpening", C.c_int32), ("debug_red", C.c_int32), ("debug_green", C.c_int32),
+                ("debug_blue", C.c_int32), ("debug_luminance", C.c_int32), ("debug_bvh", C.c_int32)]
+
+    @classmethod
+    def defaults(cls, **kw):
+        p = cls(0.5, 1.0, 1.0, 0.0, 1.0, 1.0, 0.3, 4, (C.c_double * 3)(1.0, 1.0, 1.0), 0.2, 0, 0, 0, 0, 0, 0, 0, 0)
+        for k, v in kw.items():
+            if k == "color_balance":
+                p.color_balance = (C.c_double * 3)(*v)
+            elif k == "debug":
+                p.debug_red, p.debug_green, p.debug_blue, p.debug_luminance, p.debug_bvh = [int(x) for x in v]
+            else:
+                setattr(p, k, v)
+        return p
+
+
+class ImageStats(C.Structure):
+    _fields_ = [("average_luminance", C.c_float), ("max_luminance", C.c_float), ("histogram", C.c_int32 * 256)]
+
+
 class Counters(C.Structure):
     _fields_ = [("primary_samples", C.c_uint64), ("segments", C.c_uint64), ("nodes_tested", C.c_uint64),
                 ("spheres_tested", C.c_uint64), ("triangles_tested", C.c_uint64), ("cubes_tested", C.c_uint64),
@@ -120,7 +145,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
 ]
 
@@ -155,6 +180,8 @@ def load():
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
     lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
+    lib.zr_post_process.argtypes = [vp, C.POINTER(PostParams), vp, i32, i32, i32, i32, vp]
+    lib.zr_analyze_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(ImageStats)]
     lib.zr_trace_paths.argtypes = [vp, vp, C.POINTER(Camera), u64, vp, i32, i32, vp]
     lib.zr_render_passes.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), vp, vp, vp]
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -226,6 +253,18 @@ class DemoScene:
             raise ZrError(f"drop-in render failed: {load().zr_last_error().decode()}")
         return out, ctr
 
+    def dropin_frame_to_rgb8(self, spp=0, device=0):
+        """render (auto-exposure, reflection split) + post stack through include/zenith/zenith.hpp: (rgb8, reflection8, exposure)"""
+        w, h = self.camera.image_width, self.camera.image_height
+        a = np.zeros((h, w, 3), dtype=np.uint8); b = np.zeros((h, w, 3), dtype=np.uint8)
+        ex = C.c_float(0)
+        lib = load_scenes()
+        lib.zrs_dropin_frame_to_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        rc = lib.zrs_dropin_frame_to_rgb8(self._h, spp, device, a.ctypes.data, b.ctypes.data, C.byref(ex))
+        if rc != 0:
+            raise ZrError(f"drop-in frame pipeline failed ({rc}): {load().zr_last_error().decode()}")
+        return a, b, ex.value
+
     def close(self):
         if self._h:
             load_scenes().zrs_free(self._h)
@@ -256,6 +295,20 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def post_process(self, params, frame, is_data_pass=False, apply_gamma=True):
+        """camera::process_framebuffer_to_image up to the PNG encoder: (H, W, 3) float64 -> (H, W, 3) uint8"""
+        frame = np.ascontiguousarray(frame, dtype=np.float64)
+        h, w = frame.shape[:2]
+        out = np.zeros((h, w, 3), dtype=np.uint8)
+        _check(self.lib.zr_post_process(self._c, C.byref(params), frame.ctypes.data, w, h, int(is_data_pass), int(apply_gamma), out.ctypes.data))
+        return out
+
+    def analyze_frame(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.float64)
+        st = ImageStats()
+        _check(self.lib.zr_analyze_frame(self._c, frame.ctypes.data, frame.size // 3, C.byref(st)))
+        return st
 
     def counters(self):
         c = Counters()

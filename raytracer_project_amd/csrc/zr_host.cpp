@@ -1139,6 +1139,48 @@ int zr_render_passes(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const z
     return ZR_OK;
 }
 
+int zr_post_process(zr_ctx* c, const zr_post_params* pp, const double* frame, int W, int H, int is_data_pass, int apply_gamma, uint8_t* out) {
+    if (!c || !pp || !frame || !out) return fail(ZR_E_INVALID, "null argument");
+    if (W < 2 || H < 2 || (size_t)W * H > (1ull << 31)) return fail(ZR_E_INVALID, "frame size %d x %d not supported", W, H);
+    if (pp->use_bloom && (pp->bloom_radius < 0 || pp->bloom_radius > 4096)) return fail(ZR_E_INVALID, "bloom radius out of range");
+    HIP_OK(hipSetDevice(c->device));
+    const size_t n = (size_t)W * H;
+    DevBuf<double> d_frame, t0, t1, t2; DevBuf<uint8_t> d_out;
+    int rc;
+    if ((rc = d_frame.alloc(n * 3)) || (rc = d_out.alloc(n * 3))) return rc;
+    const bool bloom = !is_data_pass && pp->use_bloom, sharpen = !is_data_pass && pp->use_sharpening;
+    if (bloom && ((rc = t0.alloc(n * 3)) || (rc = t1.alloc(n * 3)))) return rc;
+    if (sharpen && (rc = t2.alloc(n * 3))) return rc;
+    HIP_OK(hipMemcpyAsync(d_frame.p, frame, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const double ev = std::pow(2.0, (double)pp->exposure);   // camera.hpp:711
+    HIP_OK(zr::launch_post(d_frame.p, W, H, *pp, is_data_pass, apply_gamma, ev, t0.p, t1.p, t2.p, d_out.p, c->stream));
+    HIP_OK(hipMemcpyAsync(out, d_out.p, n * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return ZR_OK;
+}
+
+int zr_analyze_frame(zr_ctx* c, const double* frame, size_t n, zr_image_stats* out) {
+    if (!c || !frame || !out) return fail(ZR_E_INVALID, "null argument");
+    if (n == 0 || n > (1ull << 31)) return fail(ZR_E_INVALID, "pixel count not supported");
+    HIP_OK(hipSetDevice(c->device));
+    const size_t blocks = (n + 255) / 256;
+    DevBuf<double> d_frame, d_log; DevBuf<float> d_max; DevBuf<int> d_hist;
+    int rc;
+    if ((rc = d_frame.alloc(n * 3)) || (rc = d_log.alloc(blocks)) || (rc = d_max.alloc(blocks)) || (rc = d_hist.alloc(256))) return rc;
+    HIP_OK(hipMemcpyAsync(d_frame.p, frame, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(zr::launch_analyze(d_frame.p, n, d_log.p, d_max.p, d_hist.p, c->stream));
+    std::vector<double> plog(blocks); std::vector<float> pmax(blocks);
+    HIP_OK(hipMemcpyAsync(plog.data(), d_log.p, blocks * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(pmax.data(), d_max.p, blocks * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(out->histogram, d_hist.p, 256 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    double total = 0.0; float mx = 0.0f;
+    for (size_t b = 0; b < blocks; b++) { total += plog[b]; if (pmax[b] > mx) mx = pmax[b]; }
+    out->max_luminance = mx;
+    out->average_luminance = std::pow(2.0f, static_cast<float>(total / (double)n));   // color_processing.hpp:180
+    return ZR_OK;
+}
+
 int zr_trace_paths(zr_ctx* c, const zr_scene* s, const zr_camera* cam, uint64_t seed, const int32_t* requests, int n, int max_segments, double* out) {
     if (!c || !s || !cam || (n > 0 && (!requests || !out))) return fail(ZR_E_INVALID, "null argument");
     if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_trace_paths");

@@ -51,6 +51,9 @@ hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const
                       double* out_albedo, double* out_normal, double* out_zdepth, hipStream_t stream);
 hipError_t launch_passes(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out_beauty,
                          double* out_reflection, double* out_refraction, unsigned long long* gctr, hipStream_t stream);
+hipError_t launch_post(const double* d_frame, int W, int H, const zr_post_params& pp, int is_data_pass, int apply_gamma, double ev, double* d_tmp0,
+                       double* d_tmp1, double* d_tmp2, uint8_t* d_out, hipStream_t stream);
+hipError_t launch_analyze(const double* d_frame, size_t n, double* d_part_log, float* d_part_max, int* d_hist, hipStream_t stream);
 #define ZR_PATH_REC 17
 hipError_t launch_path_records(const DScene& sc, const DCamera& cam, uint64_t seed, const int32_t* req, int n_req, int max_seg, double* out,
                                hipStream_t stream);

@@ -71,6 +71,39 @@ int zrs_render_dropin(void* p, int width, int height, int spp, int device, doubl
     return 0;
 }
 
+// The reference's whole frame pipeline through the drop-in API: render with auto-exposure and the reflection / refraction
+// split, then the beauty image through the post stack (bloom + sharpening + ACES) and the reflection frame as a data pass —
+// what main.cpp's render thread followed by save_render_pass(RGB) / save_render_pass(REFLECTIONS) does.
+// rgb8 / refl8: W*H*3 bytes each; exposure_out: the auto-exposure value written back to post.exposure (camera.hpp:258-266)
+int zrs_dropin_frame_to_rgb8(void* p, int spp, int device, unsigned char* rgb8, unsigned char* refl8, float* exposure_out) {
+    handle* h = (handle*)p;
+    camera cam;
+    const zr_camera& c = h->s.cam;
+    cam.image_width = c.image_width; cam.image_height = c.image_height;
+    cam.samples_per_pixel = spp > 0 ? spp : c.samples_per_pixel;
+    cam.max_depth = c.max_depth; cam.vfov = c.vfov;
+    cam.lookfrom = point3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
+    cam.lookat = point3(c.lookat[0], c.lookat[1], c.lookat[2]);
+    cam.vup = vec3(c.vup[0], c.vup[1], c.vup[2]);
+    cam.defocus_angle = c.defocus_angle; cam.focus_dist = c.focus_dist;
+    cam.seed = h->s.seed; cam.device = device;
+    cam.use_reflection = true;
+    cam.reset_accumulator();
+    post_processor post;
+    post.use_auto_exposure = true; post.exposure_compensation_stops = 0.5f;
+    post.use_bloom = true; post.bloom_threshold = 0.8f; post.use_sharpening = true; post.use_aces_tone_mapping = true;
+    std::atomic<bool> flag{true};
+    auto bvh_world = make_shared<bvh_node>(h->s.world);
+    cam.render(*bvh_world, h->s.env, post, flag);
+    if (cam.lines_rendered.load() != cam.image_height) return -1;
+    std::vector<unsigned char> a, b;
+    if (!cam.process_framebuffer(cam.render_accumulator, post, a) || !cam.process_framebuffer(cam.reflection_buffer, post, b, true, true)) return -2;
+    std::memcpy(rgb8, a.data(), a.size());
+    std::memcpy(refl8, b.data(), b.size());
+    if (exposure_out) *exposure_out = post.exposure;
+    return 0;
+}
+
 }  // extern "C"
 
 // sizes of the ABI structs as the C++ compiler sees them (tests compare them with the ctypes mirrors)

@@ -71,6 +71,13 @@ PASSES = {
     "passes_cfg5": ("cfg5", 150, 350, 32, 24, 32, []),
 }
 
+# the post stack (bloom, sharpen, process, 8-bit; analyze_framebuffer) through the genuine post_processor / bloom_filter:
+# (scene, spp of the input frame, presets of `zenith_ref post`)
+POSTS = {
+    "post_cfg1": ("cfg1", 4, [0, 1, 2, 3, 4, 5, 6, 7]),
+    "post_mix0": ("mix0", 8, [1, 3]),
+}
+
 
 def run(*args):
     p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
@@ -129,6 +136,19 @@ def main():
             np.savez_compressed(os.path.join(HERE, name + ".npz"), beauty=np.load(pre + "_beauty.npy"), reflection=np.load(pre + "_reflection.npy"),
                                 refraction=np.load(pre + "_refraction.npy"), meta=np.array(json.dumps(meta)))
             print(name, meta)
+        for name, (scene, spp, presets) in POSTS.items():
+            if want and name not in want and scene not in want:
+                continue
+            arrays, metas = {}, []
+            for k in presets:
+                pre = os.path.join(tmp, f"{name}_{k}")
+                meta = run("post", scene, k, pre, spp)
+                metas.append(meta)
+                arrays["frame"] = np.load(pre + "_frame.npy")      # the same input frame for every preset
+                arrays[f"rgb8_{k}"] = np.load(pre + "_rgb8.npy")
+                arrays["hist"] = np.load(pre + "_hist.npy")
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(json.dumps(metas)), **arrays)
+            print(name, [m["preset"] for m in metas])
         if not want or "texels" in want:
             out = os.path.join(tmp, "texels.npy")
             subprocess.run([REF, "texels", "64", "32", out], check=True)
