@@ -31,11 +31,13 @@ WORKLOADS = {
     "cfg2": ("cfg2", (), "Shirley random spheres (485 spheres), 1280x720, 256 spp, depth 50"),
     "cfg5": ("cfg5", (), "Cornell box: cubes + constant_medium + dielectric, 600x600, 1024 spp, depth 50"),
     "cfg1": ("cfg1", (), "3 Lambertian spheres, 400x225, 16 spp, depth 8"),
+    "cfg3w": ("cfg3w", (), "cfg3 with the mesh placed as the reference places meshes: 1M triangles under material_instance -> rotate_x -> "
+                           "rotate_z -> translate, 1920x1080, 512 spp, depth 10"),
     "demo": ("demo", (), "the reference's demo workload (scene_management.hpp:103-236): ~900 scaled/rotated/re-materialed instances, "
                          "a wrapped 3840-triangle mesh, fog volume, 1280x720, 128 spp, depth 10"),
 }
 # bounded CPU-baseline samples (zenith_ref `time` arguments: xstep ystep spp), sized for ~10-30 s on 16 host threads
-CPU_SAMPLE = {"cfg3": (4, 4, 128), "cfg2": (4, 4, 48), "cfg5": (4, 4, 48), "cfg1": (1, 1, 16), "demo": (4, 4, 32)}
+CPU_SAMPLE = {"cfg3": (4, 4, 128), "cfg2": (4, 4, 48), "cfg5": (4, 4, 48), "cfg1": (1, 1, 16), "demo": (4, 4, 32), "cfg3w": (4, 4, 128)}
 
 
 def cpu_baseline(workload, threads):

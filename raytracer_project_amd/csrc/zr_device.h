@@ -296,6 +296,7 @@ __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r
     rec.p = p;
     rec.mat = (uint32_t)__double_as_longlong(v[18]);
     set_face(rec, r.d, smooth);
+    if ((uint32_t)__double_as_longlong(v[19]) & 1u) rec.front = true;   // baked from under a translate / rotate_y (zr_host.cpp)
     // u, v, tangent, bitangent are not written by triangle::hit: fresh-record values
     rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
 }

@@ -59,7 +59,8 @@ struct DScene {
     const uint32_t* sphere_mat;
     const double* tri_v;        // 9 per triangle
     const double* tri_s;        // shading record, 20 doubles (160 B, two 128-B lines at any 32-B phase) per triangle:
-                                // [0..8] vertices, [9..17] vertex normals, [18] low word = material id
+                                // [0..8] vertices, [9..17] vertex normals (need not be unit), [18] low word = material id,
+                                // [19] low word bit 0 = front_face forced true (triangle baked from under a translate / rotate_y)
     const double* cubes;        // 6 per cube: half extents, centre
     const uint32_t* cube_mat;
     const DMedium* media;

@@ -306,13 +306,60 @@ struct Flattener {
             }
         }
     }
+    // A triangle under a chain of translate / rotate_x,y,z / material_instance wrappers is stored in WORLD space as a bare
+    // triangle: vertices and (un-normalised) vertex normals mapped object -> world with the wrappers' own forward maps
+    // (translate.hpp:24-27, rotate_*.hpp hit(): the maps apply_op_rec uses for hit points), material = the outermost
+    // material_instance, plus a flag when the chain holds a translate or a rotate_y, which force front_face = true
+    // (SURVEY §8 a-17 quirk).  t is the same in both spaces (the wrappers do not normalise the transformed direction), so
+    // only the last bits of the hit differ from transforming the ray — and every mesh the reference's scenes place in the
+    // world (model -> material_instance -> rotate -> translate) runs on the bare-triangle fast path instead of paying a
+    // chain transform per candidate.  scale is excluded: it would change which triangles count as degenerate.
+    const std::vector<uint8_t>* baked = nullptr;   // per object
+    size_t n_baked = 0;
+    uint32_t append_baked_triangle(const zr_object& o) {
+        double v[9], nn[9];
+        std::memcpy(v, &s.tri_v[(size_t)o.index * 9], sizeof v);
+        std::memcpy(nn, &s.tri_n[(size_t)o.index * 9], sizeof nn);
+        uint32_t mat = s.tri_mat[o.index];
+        bool force_front = false;
+        for (int k = (int)o.chain_count - 1; k >= 0; k--) {   // innermost wrapper first, as the hit record travels outwards
+            const zr_xform_op& op = s.ops[o.chain_first + k];
+            const double sn = op.a[0], co = op.a[1];
+            for (int c = 0; c < 3; c++) {
+                double* p = v + 3 * c; double* q = nn + 3 * c;
+                switch (op.kind) {
+                    case ZR_OP_TRANSLATE: p[0] += op.a[0]; p[1] += op.a[1]; p[2] += op.a[2]; break;
+                    case ZR_OP_ROTATE_Y: { double x = p[0], z = p[2]; p[0] = co * x - sn * z; p[2] = sn * x + co * z;
+                                           x = q[0]; z = q[2]; q[0] = co * x - sn * z; q[2] = sn * x + co * z; } break;
+                    case ZR_OP_ROTATE_X: { double y = p[1], z = p[2]; p[1] = co * y - sn * z; p[2] = sn * y + co * z;
+                                           y = q[1]; z = q[2]; q[1] = co * y - sn * z; q[2] = sn * y + co * z; } break;
+                    case ZR_OP_ROTATE_Z: { double x = p[0], y = p[1]; p[0] = co * x - sn * y; p[1] = sn * x + co * y;
+                                           x = q[0]; y = q[1]; q[0] = co * x - sn * y; q[1] = sn * x + co * y; } break;
+                    default: break;
+                }
+            }
+            if (op.kind == ZR_OP_TRANSLATE || op.kind == ZR_OP_ROTATE_Y) force_front = true;
+            if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+        }
+        tri_v.insert(tri_v.end(), v, v + 9);
+        tri_s.insert(tri_s.end(), v, v + 9);
+        tri_s.insert(tri_s.end(), nn, nn + 9);
+        uint64_t mbits = mat, fbits = force_front ? 1u : 0u;
+        double md, fd; std::memcpy(&md, &mbits, 8); std::memcpy(&fd, &fbits, 8);
+        tri_s.push_back(md); tri_s.push_back(fd);
+        n_baked++;
+        return (uint32_t)(tri_s.size() / 20) - 1;
+    }
     // returns the first device index of the leaf's objects within its kind's array
     uint32_t append_leaf(const zr::BuildNode& n) {
         uint32_t first = 0;
         for (uint32_t k = 0; k < n.count; k++) {
-            const zr_object& o = objs[br.order[n.first + k]];
+            const uint32_t oi = br.order[n.first + k];
+            const zr_object& o = objs[oi];
             uint32_t di;
-            if (n.kind == ZR_KIND_WRAPPED) {
+            if (baked && (*baked)[oi]) {
+                di = append_baked_triangle(o);
+            } else if (n.kind == ZR_KIND_WRAPPED) {
                 // reserve the slot order: inner primitives first would break contiguity of wrapped[] — it does not,
                 // wrapped[] only grows here
                 zr::DWrapped w{};
@@ -662,10 +709,17 @@ int zr_scene_commit(zr_scene* s) {
     Boxer boxer{*s};
     std::vector<zr::BuildBox> boxes(objs.size());
     std::vector<uint32_t> kinds(objs.size());
+    std::vector<uint8_t> baked(objs.size(), 0);
+    const bool bake = env_double("ZR_BAKE_TRIANGLES", 1) != 0;
     for (size_t k = 0; k < objs.size(); k++) {
         const zr_object& o = objs[k];
         boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
         kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
+        if (bake && o.type == ZR_PRIM_TRIANGLE && o.chain_count > 0) {   // see Flattener::append_baked_triangle
+            bool ok = true;
+            for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
+            if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
+        }
         for (int a = 0; a < 3; a++)
             if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", k);
     }
@@ -677,6 +731,7 @@ int zr_scene_commit(zr_scene* s) {
     if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
 
     Flattener fl{*s, objs, br};
+    fl.baked = &baked;
     fl.open_ratio = env_double("ZR_BVH_OPEN_RATIO", 1.25);
     fl.run();
 

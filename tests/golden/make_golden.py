@@ -39,6 +39,7 @@ TILES = {
     # the reference's own demo workload (scene_management.hpp:103-236): 900 instanced prefabs, a wrapped mesh, fog
     "demo_tile": ("demo", 560, 300, 48, 32, 32, False, []),          # mesh + mirror sphere + glass cube
     "demo_tile_b": ("demo", 200, 420, 40, 24, 32, True, []),         # the instance grid through the fog
+    "cfg3w_small": ("cfg3w", 900, 500, 24, 24, 64, False, [200, 20, 256, 128]),
 }
 TRACES = {
     # name -> (scene, rays, seed, probe-box clamp lo, hi, extra scene args)
@@ -48,6 +49,7 @@ TRACES = {
     "trace_cfg3_small": ("cfg3", 2048, 14, -4, 4, [200, 20, 256, 128]),
     "trace_mesh0": ("mesh0", 4096, 15, -3, 4, []),
     "trace_demo": ("demo", 4096, 16, -16, 16, []),
+    "trace_cfg3w_small": ("cfg3w", 4096, 17, -4, 4, [200, 20, 256, 128]),   # a placed (wrapped) mesh: baked to world space on the device
     # adversarial rays (ZR_TRACE_ADVERSARIAL: zero direction components, tiny/large scales, round and far origins)
     "trace_adv_mix0": ("mix0", 4096, 21, -6, 6, [], True),
     "trace_adv_cfg2": ("cfg2", 4096, 22, -12, 12, [], True),
