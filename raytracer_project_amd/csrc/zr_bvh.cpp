@@ -90,10 +90,14 @@ struct Builder {
                     grow(bb[bi], b); bc[bi]++; bw[bi] += ck[kinds[o] & 7];
                 }
                 double la[kBins], lw[kBins]; BuildBox acc = empty_box(); double w = 0;
-                for (int b = 0; b < kBins - 1; b++) { if (bc[b]) grow(acc, bb[b]); w += bw[b]; la[b] = half_area(acc); lw[b] = w; }
+                for (int b = 0; b < kBins - 1; b++) {
+                    if (bc[b]) grow(acc, bb[b]);
+                    w += bw[b]; la[b] = half_area(acc); lw[b] = w;
+                }
                 acc = empty_box(); w = 0;
                 for (int b = kBins - 1; b > 0; b--) {
-                    if (bc[b]) grow(acc, bb[b]); w += bw[b];
+                    if (bc[b]) grow(acc, bb[b]);
+                    w += bw[b];
                     if (lw[b - 1] == 0 || w == 0) continue;
                     double cost = la[b - 1] * lw[b - 1] + half_area(acc) * w;
                     if (cost < best) { best = cost; best_axis = ax; best_bin = b; }
