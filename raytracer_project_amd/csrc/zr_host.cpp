@@ -273,12 +273,15 @@ struct Flattener {
     std::vector<zr::DMedium> media;
     std::vector<zr::DWrapped> wrapped;
 
-    uint32_t append_prim(uint32_t type, uint32_t idx) {
+    static constexpr uint32_t kKeepMaterial = 0xFFFFFFFEu;
+    // `mat` != kKeepMaterial: the primitive sits under material_instance wrappers only, which do nothing but replace rec.mat
+    // (material_instance.hpp:12-28) — it is stored bare with the outermost instance's material
+    uint32_t append_prim(uint32_t type, uint32_t idx, uint32_t mat = kKeepMaterial) {
         switch (type) {
             case ZR_PRIM_SPHERE: {
                 const double* q = &s.spheres[(size_t)idx * 4];
                 spheres.insert(spheres.end(), {q[0], q[1], q[2], std::fmax(0, q[3])});  // sphere.hpp:9
-                sphere_mat.push_back(s.sphere_mat[idx]);
+                sphere_mat.push_back(mat != kKeepMaterial ? mat : s.sphere_mat[idx]);
                 return (uint32_t)sphere_mat.size() - 1;
             }
             case ZR_PRIM_TRIANGLE: {
@@ -292,7 +295,7 @@ struct Flattener {
             }
             case ZR_PRIM_CUBE: {
                 cubes.insert(cubes.end(), &s.cubes[(size_t)idx * 12], &s.cubes[(size_t)idx * 12] + 6);
-                cube_mat.push_back(s.cube_mat[idx]);
+                cube_mat.push_back(mat != kKeepMaterial ? mat : s.cube_mat[idx]);
                 return (uint32_t)cube_mat.size() - 1;
             }
             default: {
@@ -357,8 +360,11 @@ struct Flattener {
             const uint32_t oi = br.order[n.first + k];
             const zr_object& o = objs[oi];
             uint32_t di;
-            if (baked && (*baked)[oi]) {
+            if (baked && (*baked)[oi] == 1) {
                 di = append_baked_triangle(o);
+            } else if (baked && (*baked)[oi] == 2) {
+                di = append_prim(o.type, o.index, s.ops[o.chain_first].mat);   // the outermost wrapper is applied last
+                n_baked++;
             } else if (n.kind == ZR_KIND_WRAPPED) {
                 // reserve the slot order: inner primitives first would break contiguity of wrapped[] — it does not,
                 // wrapped[] only grows here
@@ -719,6 +725,11 @@ int zr_scene_commit(zr_scene* s) {
             bool ok = true;
             for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
             if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
+        }
+        if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
+            bool only_material = true;
+            for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
+            if (only_material) { baked[k] = 2; kinds[k] = o.type; }
         }
         for (int a = 0; a < 3; a++)
             if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", k);
