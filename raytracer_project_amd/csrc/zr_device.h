@@ -268,6 +268,7 @@ __device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, 
     V3 outward = vdiv(rec.p - center, s[3]);
     set_face(rec, r.d, outward);
     rec.mat = sc.sphere_mat[idx];
+    if (rec.mat != 0xFFFFFFFFu && (rec.mat & 0x80000000u)) { rec.mat &= 0x7FFFFFFFu; rec.front = true; }   // baked from under a translate (zr_host.cpp)
     if (!full && !mat_needs_uv(sc, rec.mat)) { rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0); return; }
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + 3.14159265358979323846;

@@ -353,6 +353,25 @@ struct Flattener {
         n_baked++;
         return (uint32_t)(tri_s.size() / 20) - 1;
     }
+    // A sphere under uniform scale / translate / material_instance wrappers (the demo scene's instanced spheres:
+    // scale -> material_instance -> translate) is the sphere (c s + offset, r s): same t, same unit normal, same u/v and
+    // tangent (no rotation involved); bit 31 of its material word records the front_face = true a translate forces.
+    uint32_t append_baked_sphere(const zr_object& o) {
+        const double* q = &s.spheres[(size_t)o.index * 4];
+        double c[3] = {q[0], q[1], q[2]}, r = std::fmax(0, q[3]);
+        uint32_t mat = s.sphere_mat[o.index];
+        bool force_front = false;
+        for (int k = (int)o.chain_count - 1; k >= 0; k--) {
+            const zr_xform_op& op = s.ops[o.chain_first + k];
+            if (op.kind == ZR_OP_SCALE) { for (double& x : c) x *= op.a[0]; r *= op.a[0]; }
+            else if (op.kind == ZR_OP_TRANSLATE) { c[0] += op.a[0]; c[1] += op.a[1]; c[2] += op.a[2]; force_front = true; }
+            else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+        }
+        spheres.insert(spheres.end(), {c[0], c[1], c[2], r});
+        sphere_mat.push_back(force_front ? (mat | 0x80000000u) : mat);
+        n_baked++;
+        return (uint32_t)sphere_mat.size() - 1;
+    }
     // returns the first device index of the leaf's objects within its kind's array
     uint32_t append_leaf(const zr::BuildNode& n) {
         uint32_t first = 0;
@@ -362,6 +381,8 @@ struct Flattener {
             uint32_t di;
             if (baked && (*baked)[oi] == 1) {
                 di = append_baked_triangle(o);
+            } else if (baked && (*baked)[oi] == 3) {
+                di = append_baked_sphere(o);
             } else if (baked && (*baked)[oi] == 2) {
                 di = append_prim(o.type, o.index, s.ops[o.chain_first].mat);   // the outermost wrapper is applied last
                 n_baked++;
@@ -725,6 +746,17 @@ int zr_scene_commit(zr_scene* s) {
             bool ok = true;
             for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
             if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
+        }
+        if (bake && o.type == ZR_PRIM_SPHERE && o.chain_count > 0) {   // see Flattener::append_baked_sphere
+            bool ok = true, moved = false; uint32_t mat = s->sphere_mat[o.index];
+            for (int q = (int)o.chain_count - 1; q >= 0 && ok; q--) {
+                const zr_xform_op& op = s->ops[o.chain_first + q];
+                if (op.kind == ZR_OP_SCALE) { ok = op.a[0] > 0 && op.a[0] == op.a[1] && op.a[1] == op.a[2]; moved = true; }
+                else if (op.kind == ZR_OP_TRANSLATE) moved = true;
+                else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+                else ok = false;
+            }
+            if (ok && moved && mat < 0x7FFFFFFFu) { baked[k] = 3; kinds[k] = ZR_PRIM_SPHERE; }
         }
         if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
             bool only_material = true;
