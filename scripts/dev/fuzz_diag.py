@@ -1,0 +1,26 @@
+"""Development aid (GPU): details of the rays on which a fuzz scene (tests/test_fuzz_scenes.py) disagrees with the oracle."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracer_project_amd import capi
+from oracle import zr_oracle_py as zo
+import test_fuzz_scenes as fz
+ctx = capi.Context(0)
+np.set_printoptions(precision=17, linewidth=220)
+for seed in [int(a) for a in sys.argv[1:]]:
+    rng = np.random.default_rng(1000 + seed)
+    k = fz._random_scene(capi, rng, n_obj=int(rng.integers(6, 60)))
+    osc = zo.OracleScene(k.desc); sc = capi.Scene(ctx, k.desc)
+    n = 4000
+    o = rng.uniform(-6, 6, (n, 3)); tgt = rng.uniform(-2.5, 2.5, (n, 3))
+    rays = np.concatenate([o, tgt - o], axis=1)
+    ho = osc.trace(rays, seed=3, pixel=9, bounce=0)
+    for engine in ("extend", "pairs"):
+        os.environ["ZR_TRACE_ENGINE"] = engine
+        hg = sc.trace(rays, seed=3, pixel=9, bounce=0)
+        bad = np.nonzero(hg["mat"] != ho["mat"])[0]
+        print("seed", seed, engine, "mismatches", bad.tolist())
+        for i in bad[:3]:
+            print("   ray", rays[i]); print("   gpu t", hg["t"][i], "mat", hg["mat"][i], "p", hg["p"][i], "n", hg["normal"][i])
+            print("   ora t", ho["t"][i], "mat", ho["mat"][i], "p", ho["p"][i], "n", ho["normal"][i])
