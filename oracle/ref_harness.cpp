@@ -527,43 +527,43 @@ int main(int argc, char** argv) {
             default: return usage();
         }
         // camera.hpp:707-733
-        std::vector<color> bloom_buffer = buffer;
-        double ev_multiplier = std::pow(2.0, (double)pp.exposure);
+        std::vector<color> work = buffer;
+        double ev = std::pow(2.0, (double)pp.exposure);
         if (!is_data_pass && pp.use_bloom) {
-            for (auto& pix : bloom_buffer) pix *= ev_multiplier;
-            std::vector<color> bloom_overlay(bloom_buffer.size(), color(0.0, 0.0, 0.0));
+            for (auto& pix : work) pix *= ev;
+            std::vector<color> glow(work.size(), color(0.0, 0.0, 0.0));
             bloom_filter bloom(pp.bloom_threshold, pp.bloom_intensity, pp.bloom_radius);
-            bloom.generate_bloom_overlay(bloom_buffer, bloom_overlay, W, H, 1.0f);
-            double inv_ev = 1.0 / ev_multiplier;
-            for (size_t i = 0; i < bloom_buffer.size(); ++i) bloom_buffer[i] = buffer[i] + (bloom_overlay[i] * inv_ev);
+            bloom.generate_bloom_overlay(work, glow, W, H, 1.0f);
+            double back = 1.0 / ev;
+            for (size_t i = 0; i < work.size(); ++i) work[i] = buffer[i] + (glow[i] * back);
         } else {
-            bloom_buffer = buffer;
+            work = buffer;
         }
-        if (!is_data_pass && pp.use_sharpening) pp.apply_sharpening(bloom_buffer, W, H, pp.sharpen_amount);
-        std::vector<unsigned char> image_data((size_t)W * H * 3);
+        if (!is_data_pass && pp.use_sharpening) pp.apply_sharpening(work, W, H, pp.sharpen_amount);
+        std::vector<unsigned char> bytes((size_t)W * H * 3);
         for (int j = 0; j < H; j++)
             for (int i = 0; i < W; i++) {
-                size_t pixel_idx = static_cast<size_t>(j) * W + i;
-                color pix_color = bloom_buffer[pixel_idx];
+                size_t k = static_cast<size_t>(j) * W + i;
+                color c3 = work[k];
                 if (!is_data_pass) {
-                    pix_color *= ev_multiplier;
+                    c3 *= ev;
                     float u = static_cast<float>(i) / (W - 1);
                     float v = static_cast<float>(j) / (H - 1);
-                    pix_color = pp.process(pix_color, u, v, render_pass::RGB);
+                    c3 = pp.process(c3, u, v, render_pass::RGB);
                 } else {
-                    pix_color = color(std::clamp(pix_color.x(), 0.0, 1.0), std::clamp(pix_color.y(), 0.0, 1.0), std::clamp(pix_color.z(), 0.0, 1.0));
-                    if (apply_gamma) pix_color = linear_to_gamma(pix_color);
+                    c3 = color(std::clamp(c3.x(), 0.0, 1.0), std::clamp(c3.y(), 0.0, 1.0), std::clamp(c3.z(), 0.0, 1.0));
+                    if (apply_gamma) c3 = linear_to_gamma(c3);
                 }
-                size_t idx = pixel_idx * 3;
-                image_data[idx + 0] = static_cast<unsigned char>(255.999 * pix_color.x());
-                image_data[idx + 1] = static_cast<unsigned char>(255.999 * pix_color.y());
-                image_data[idx + 2] = static_cast<unsigned char>(255.999 * pix_color.z());
+                size_t idx = k * 3;
+                bytes[idx + 0] = static_cast<unsigned char>(255.999 * c3.x());
+                bytes[idx + 1] = static_cast<unsigned char>(255.999 * c3.y());
+                bytes[idx + 2] = static_cast<unsigned char>(255.999 * c3.z());
             }
         image_statistics st = pp.analyze_framebuffer(buffer);
         double auto_on; { post_processor q = pp; q.use_auto_exposure = true; q.exposure_compensation_stops = 0.5f; auto_on = q.apply_auto_exposure(st); }
         double auto_off = pp.apply_auto_exposure(st);
         write_npy(out + "_frame.npy", "<f8", {(size_t)H, (size_t)W, 3}, mean.data(), mean.size() * 8);
-        write_npy(out + "_rgb8.npy", "|u1", {(size_t)H, (size_t)W, 3}, image_data.data(), image_data.size());
+        write_npy(out + "_rgb8.npy", "|u1", {(size_t)H, (size_t)W, 3}, bytes.data(), bytes.size());
         std::vector<int32_t> hist(st.histogram, st.histogram + 256);
         write_npy(out + "_hist.npy", "<i4", {256}, hist.data(), hist.size() * 4);
         std::printf("{\"scene\": \"%s\", \"preset\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"is_data_pass\": %d, \"apply_gamma\": %d, "
