@@ -333,6 +333,31 @@ def test_path_records_match_oracle(name, ctx):
     assert (o[:, :, 6] > 0).sum() > n, "the requests barely hit anything"
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", ["cfg1_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full", "mix1_full", "mesh0_full", "demo_tile_b"])
+def test_other_kernel_variants_match_reference(name, variant, built, monkeypatch):
+    """ZR_KERNEL=0 (pixel-group megakernel) and ZR_KERNEL=1 (wave-scheduler megakernel) share the device arithmetic with the
+    default streaming pipeline but walk the pair BVH and integrate in registers: same fixtures, same bar."""
+    from raytracer_project_amd import capi
+    monkeypatch.setenv("ZR_KERNEL", str(variant))
+    c = capi.Context(0)
+    try:
+        fx = load_golden(name)
+        m = fx["meta"]
+        ds = demo_scene(m["scene"], m["scene_args"])
+        cam = ds.camera.copy()
+        cam.samples_per_pixel = m["spp"]
+        reg = capi.Region(m["x0"], m["y0"], m["w"], m["h"], 0, 0, 0, 0)
+        sc = capi.Scene(c, ds.desc)
+        out = sc.render(cam, ds.env, ds.seed, reg, count=True)
+        ctr = c.counters()
+        _check(out[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]], fx["mean"], f"{name} (variant {variant})")
+        assert (ctr.primary_samples, ctr.segments, ctr.rng_draws) == (m["w"] * m["h"] * m["spp"], m["segments"], m["draws"])
+        sc.close()
+    finally:
+        c.close()
+
+
 def test_cancellation_and_progress(ctx):
     """render_flag / lines_rendered of camera::render (camera.hpp:441, 548-552, 576-578) through the C ABI: *keep_going == 0
     stops the render with ZR_E_CANCELLED and leaves only finished work in the image; a completed render reports every row;
