@@ -120,6 +120,9 @@ extern "C" size_t zrs_sizeof(int which) {
         case 8: return sizeof(zr_counters);
         case 9: return sizeof(zr_hit);
         case 10: return sizeof(zr_scene_desc);
+        case 11: return sizeof(zr_post_params);
+        case 12: return sizeof(zr_image_stats);
+        case 13: return sizeof(zr_aov_params);
         default: return 0;
     }
 }

@@ -34,7 +34,7 @@ def test_ctypes_mirrors_match_c_structs(built):
     s.zrs_sizeof.restype = C.c_size_t
     s.zrs_sizeof.argtypes = [C.c_int]
     mirrors = [capi.XformOp, capi.Object, capi.Medium, capi.Material, capi.Texture, capi.Env, capi.Camera, capi.Region,
-               capi.Counters, capi.Hit, capi.SceneDesc]
+               capi.Counters, capi.Hit, capi.SceneDesc, capi.PostParams, capi.ImageStats, capi.AovParams]
     for k, m in enumerate(mirrors):
         assert s.zrs_sizeof(k) == C.sizeof(m), (m.__name__, s.zrs_sizeof(k), C.sizeof(m))
 
