@@ -358,6 +358,23 @@ def test_other_kernel_variants_match_reference(name, variant, built, monkeypatch
         c.close()
 
 
+def test_frames_beyond_the_streaming_limits_fall_back(ctx):
+    """The streaming pipeline packs the bounce counter into 8 bits (max_depth <= 250); a deeper camera is rendered by the
+    pixel-group megakernel automatically — same image contract, checked against the oracle (mix2: grey sky, long paths)."""
+    from oracle import zr_oracle_py as zo
+    from raytracer_project_amd import capi
+    ds = demo_scene("mix2")
+    cam = ds.camera.copy()
+    cam.max_depth, cam.samples_per_pixel = 300, 4
+    reg = capi.Region(20, 12, 40, 24, 0, 0, 0, 0)
+    gpu = gpu_scene(ctx, "mix2").render(cam, ds.env, ds.seed, reg, count=True)
+    gctr = ctx.counters()
+    cpu, cctr, _, _ = zo.OracleScene(ds.desc).render(cam, ds.env, ds.seed, reg)
+    _check(gpu, cpu, "mix2 at max_depth 300")
+    assert (gctr.segments, gctr.rng_draws, gctr.hits) == (cctr.segments, cctr.rng_draws, cctr.hits)
+    assert gctr.rounds == 0, "expected the megakernel fallback, not the streaming pipeline"
+
+
 def test_cancellation_and_progress(ctx):
     """render_flag / lines_rendered of camera::render (camera.hpp:441, 548-552, 576-578) through the C ABI: *keep_going == 0
     stops the render with ZR_E_CANCELLED and leaves only finished work in the image; a completed render reports every row;
