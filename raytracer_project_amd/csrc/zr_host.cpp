@@ -91,6 +91,9 @@ struct zr_ctx {
     DevBuf<unsigned char> d_pool;
     DevBuf<uint32_t> d_pixels;
     DevBuf<double> d_partial;
+    DevBuf<uint32_t> d_kend;               // reflection / refraction split: (draws, segments) of every unit's beauty path
+    DevBuf<unsigned char> d_cls;           // ... and the class of its second path
+    DevBuf<unsigned long long> d_cpart;    // ... and the per-block counters of the two passes
     DevBuf<unsigned int> d_ctl;
     DevBuf<unsigned char> d_st_overflow;
     int st_blocks = 0;
@@ -624,7 +627,7 @@ void zr_destroy(zr_ctx* c) {
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_ctr.release(); c->d_out.release(); c->d_tiles.release();
-    c->d_pool.release(); c->d_pixels.release(); c->d_partial.release(); c->d_ctl.release(); c->d_st_overflow.release();
+    c->d_pool.release(); c->d_pixels.release(); c->d_partial.release(); c->d_kend.release(); c->d_cls.release(); c->d_cpart.release(); c->d_ctl.release(); c->d_st_overflow.release();
     c->d_task.release(); c->d_overflow.release();
     if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->st_event) (void)hipEventDestroy(c->st_event);
@@ -949,8 +952,9 @@ struct HostTimer : zr::StreamTimer {
 
 // variant 2: streaming wavefront pipeline (zr_stream.hip).  Synchronises the stream internally (the round loop
 // needs the active-slot count), so zr_render_device returns with the frame complete.
+// mode 0: the render; 1 / 2: beauty pass and replay pass of the reflection / refraction split (zr_stream.hip, stream_shade)
 int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr::DEnv& de, uint64_t seed, const Plan& plan, int count,
-                  double* d_out, hipStream_t stream, volatile const uint8_t* keep_going) {
+                  double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, int mode = 0, double* d_out2 = nullptr) {
     // pixel list (cached per plan)
     std::vector<int32_t> key = {plan.W, plan.H, plan.ts, plan.x0, plan.y0, plan.x1, plan.y1, (int32_t)plan.tiles.size(),
                                 plan.tiles.empty() ? -1 : plan.tiles.front(), plan.tiles.empty() ? -1 : plan.tiles.back()};
@@ -989,6 +993,13 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
     if (keep_going) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame reduces what exists
+    if (mode != 0) {
+        if (c->d_kend.n < units * 2) { if ((rc = c->d_kend.alloc(units * 2))) return rc; }
+        if (c->d_cls.n < units) { if ((rc = c->d_cls.alloc(units))) return rc; }
+        if (mode == 2) HIP_OK(hipMemsetAsync(c->d_cls.p, 0, units, stream));
+        const size_t cp = ((size_t)c->st_slots / 256 + ST_MAX_POOLS + 1) * 4;
+        if (c->d_cpart.n < cp) { if ((rc = c->d_cpart.alloc(cp))) return rc; }
+    }
     HostTimer timer(c);
     int rounds = 0;
     hipStream_t streams[ST_MAX_POOLS];
@@ -998,7 +1009,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->generic_leaves);
+                                     keep_going, &rounds, s->generic_leaves, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));
@@ -1008,6 +1019,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
 
 int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const Plan& plan, int count,
                    double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done) {
+    c->last_rounds = 0;
     zr::DCamera dc; make_camera(*cam, dc);
     zr::DEnv de; make_env(*env, de);
     if (de.mode > ZR_ENV_SOLID_COLOR) return fail(ZR_E_INVALID, "unknown environment mode %u", de.mode);
@@ -1217,9 +1229,28 @@ int zr_render_passes(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const z
     wd.tiles = c->d_tiles.p; wd.n_tiles = (int32_t)tiles.size(); wd.tile_size = plan.ts; wd.tiles_x = plan.tiles_x;
     wd.x0 = plan.x0; wd.y0 = plan.y0; wd.x1 = plan.x1; wd.y1 = plan.y1;
     wd.lanes_per_pixel = 64; while (wd.lanes_per_pixel > dc.spp) wd.lanes_per_pixel >>= 1;
-    c->render_id++; c->last_counted = true; c->last_rounds = 0;
-    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
-    HIP_OK(zr::launch_passes(s->ds, dc, de, seed, wd, d_b.p, d_r.p, d_f.p, c->d_ctr.p, c->stream));
+    const uint64_t stream_units = (uint64_t)plan.tiles.size() * plan.ts * plan.ts * (uint64_t)dc.spp;
+    const bool streaming = c->variant == 2 && s->quad_ok && 2 * dc.max_depth <= 250 && stream_units <= 0xFFFFFFFFull && plan.W <= 65535 &&
+                           plan.H <= 65535 && env_double("ZR_PASSES_STREAM", 1) != 0;
+    if (streaming) {
+        // two runs of the streaming pipeline: the beauty pass records where every sample's stream stopped, the replay pass traces
+        // the camera ray again and runs the second path from there (stream_shade MODE 1 / 2)
+        unsigned long long ha[16], hb[16];
+        if ((rc = render_stream(c, s, dc, de, seed, plan, 0, d_b.p, c->stream, nullptr, 1))) return rc;
+        HIP_OK(hipMemcpy(ha, c->d_ctr.p, sizeof ha, hipMemcpyDeviceToHost));
+        if ((rc = render_stream(c, s, dc, de, seed, plan, 0, d_r.p, c->stream, nullptr, 2, d_f.p))) return rc;
+        HIP_OK(hipMemcpy(hb, c->d_ctr.p, sizeof hb, hipMemcpyDeviceToHost));
+        // counted by SHADE in both passes (EXTEND runs uninstrumented): samples, segments, hits, draws
+        unsigned long long h[16] = {0};
+        h[0] = (unsigned long long)c->d_pixels.n * (unsigned long long)dc.spp;   // every sample of the region, once
+        h[1] = ha[1] + hb[1]; h[7] = ha[7] + hb[7]; h[8] = ha[8] + hb[8];
+        HIP_OK(hipMemcpy(c->d_ctr.p, h, sizeof h, hipMemcpyHostToDevice));
+        c->last_counted = true;
+    } else {
+        c->render_id++; c->last_counted = true; c->last_rounds = 0;
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_OK(zr::launch_passes(s->ds, dc, de, seed, wd, d_b.p, d_r.p, d_f.p, c->d_ctr.p, c->stream));
+    }
     HIP_OK(hipStreamSynchronize(c->stream));
     std::vector<double> frame(npx * 3);
     auto copy_out = [&](DevBuf<double>& d, double* out) -> int {

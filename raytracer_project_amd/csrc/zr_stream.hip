@@ -32,7 +32,7 @@ namespace zr {
 #define ST_CHUNK 256    /* rays a wave reserves per global atomic */
 #endif
 #ifndef ST_SHADE_WAVES
-#define ST_SHADE_WAVES 2 /* 256-thread blocks per CU (= waves per SIMD) the SHADE kernel must fit */
+#define ST_SHADE_WAVES 4 /* waves per SIMD the SHADE kernel must fit (128 VGPRs): its natural allocation sits at 126-129 */
 #endif
 #ifndef ST_EXT_WAVES_LEAN
 #define ST_EXT_WAVES_LEAN 6  /* same for the triangles-and-spheres-only build of EXTEND */
@@ -72,6 +72,9 @@ struct StreamBuf {
     uint32_t P, spp, n_units, n_pix;
     uint32_t unit0;           // slot k of this pool starts on unit unit0 + k
     uint32_t unit_base;       // first dynamically assigned unit (= slots of both pools)
+    uint2* kend;              // reflection / refraction split: per unit (draws, segments) the beauty path consumed
+    unsigned char* cls;       // reflection / refraction split: per unit 1 = reflection, 2 = refraction, 0 = no contribution
+    unsigned long long* cpart; // reflection / refraction split: per SHADE block (samples, segments, hits, draws), owned by that block
     __device__ __forceinline__ double* cell(int f, uint32_t slot) const { return pool + ((size_t)(slot >> 6) * SF_N + f) * 64 + (slot & 63u); }
     __device__ __forceinline__ double ld(int f, uint32_t slot) const { return *cell(f, slot); }
     __device__ __forceinline__ void st(int f, uint32_t slot, double v) const { *cell(f, slot) = v; }
@@ -385,11 +388,19 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 }
 
 // ---- SHADE: one segment of every active slot ------------------------------------------------------------------
-template <bool COUNT>
+// MODE 0: the render.  MODE 1 / 2: the two passes of the reflection / refraction split (camera.hpp:490-517) on the same pipeline:
+// 1 = the beauty pass, which also records per unit how many draws and segments its path consumed; 2 = the replay: the camera
+// ray is traced again, at its first hit the sample's stream is positioned after the beauty path (so the SECOND scatter of that
+// hit gets the draws the reference gives it), the scattered path runs as ray_color(scattered, max_depth - 1), and its
+// luma-clamped radiance times the attenuation is written with its class.
+template <bool COUNT, int MODE>
 __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
                                                     unsigned long long* __restrict__ gctr) {
     const uint32_t slot0 = blockIdx.x * 256 + threadIdx.x;
     if (slot0 < ST_SHARDS) B.ctl[16 + 32 * slot0 + 8] = 0;  // EXTEND of the next round starts from chunk 0 of every shard
+    // the split passes count through LDS into a per-block record (a global atomic per thread costs ~1.5 ms per round and word)
+    __shared__ unsigned long long s_cnt[4];
+    if (MODE != 0 && threadIdx.x < 4) s_cnt[threadIdx.x] = 0;   // ordered before its use by the partition's barriers
     // In-block partition: the 256 slots of this block are re-dealt to its threads so that slots whose ray HIT come
     // first and misses / inactive slots last.  The hit path (hit record + scatter with its rejection sampler) and the
     // miss path (background) are both long; unsorted, almost every wave runs both under half-empty exec masks.
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     }
 #endif
     bool active_after = false, want_unit = false;
-    uint32_t c_samp = 0; unsigned long long c_draws = 0;
+    uint32_t c_samp = 0, c_seg2 = 0, c_hit2 = 0; unsigned long long c_draws = 0;
     if (slot < B.P) {
         uint2 m = B.ld2(SF_MA, slot);
         if (m.y & F_ACTIVE) {
@@ -430,30 +441,55 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             int b_inner = (int)((m.y >> 8) & 0xFFu);
             const bool first = (m.y & F_FIRST) != 0;
             const int depth_inner = cam.max_depth - 1;
+            // the split passes count segments and hits here (SHADE sees every segment exactly once), so that their EXTEND can be
+            // the uninstrumented build; the replay's first segment is the beauty pass's, found again: not counted
+            if (COUNT && MODE != 0 && !(MODE == 2 && first)) { c_seg2++; if (ki.x != 0xFFFFFFFFu) c_hit2++; }
             // L, att0 and the slot's running sum are read only on the paths that need them
             bool ended = false;
             V3 contrib = mk(0, 0, 0);   // added to the slot sum when the path ends
             V3 add_now = mk(0, 0, 0);   // emission of a primary hit: added to the slot sum immediately
             bool has_add = false;
+            bool no_output = false;     // MODE 2: the sample contributes nothing to the split frames
             if (ki.x == NONE) {
-                V3 bg = background(sc, env, ray.d);
-                contrib = first ? bg : B.ld3(SF_ATT0, slot) * (B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg);  // camera.hpp:520 / 941,1000
-                ended = true;
+                if (MODE == 2 && first) { ended = true; no_output = true; }   // the primary ray saw the background only (camera.hpp:518-526)
+                else {
+                    V3 bg = background(sc, env, ray.d);
+                    if (MODE == 2) {
+                        V3 scol = B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg;
+                        const double luma = 0.2126 * len(scol);                  // camera.hpp:499-503
+                        if (luma > 2.0) scol = scol * (2.0 / luma);
+                        contrib = B.ld3(SF_ATT0, slot) * scol;
+                    } else {
+                        contrib = first ? bg : B.ld3(SF_ATT0, slot) * (B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg);  // camera.hpp:520 / 941,1000
+                    }
+                    ended = true;
+                }
             } else {
                 const double t = B.ld(SF_HIT_T, slot);
                 V3 em, att; Ray nr; bool sc_ok;
+                uint32_t cls_now = 0;
                 {
                     Rec rec;
                     object_rec(sc, ki.x, ki.y, ray, t, rec);
                     em = emitted(sc, rec);
+                    if (MODE == 2 && first) {   // the stream continues where the beauty path of this sample stopped
+                        const uint2 ke = B.kend[B.ld2(SF_MB, slot).x];
+                        g.k = ke.x; g.bounce = ke.y;
+                    }
                     sc_ok = scatter(sc, ray, rec, att, nr, g);
+                    if (MODE == 2 && first && sc_ok) {   // camera.hpp:506-516
+                        const V3 reflected_dir = reflect(unit(ray.d), unit(rec.n));
+                        if (dot(unit(nr.d), reflected_dir) > 0.9) cls_now = 1;
+                        else if (dot(nr.d, rec.n) < 0) cls_now = 2;
+                    }
                 }
                 const bool has_em = em.x != 0.0 || em.y != 0.0 || em.z != 0.0;
                 if (first) {  // ray_color_from_hit, camera.hpp:989-1004
-                    if (has_em) { add_now = em; has_add = true; }
-                    if (!sc_ok || depth_inner <= 0) ended = true;
+                    if (MODE != 2 && has_em) { add_now = em; has_add = true; }
+                    if (!sc_ok || depth_inner <= 0) { ended = true; if (MODE == 2) no_output = true; }
                     else {
                         B.st3(SF_ATT0, slot, att); B.st3(SF_L, slot, mk(0, 0, 0)); B.st3(SF_BETA, slot, mk(1, 1, 1));
+                        if (MODE == 2) { uint2 mb = B.ld2(SF_MB, slot); mb.y = cls_now; B.st2(SF_MB, slot, mb); }
                         b_inner = 0;
                     }
                 } else {      // body of ray_color's loop, camera.hpp:944-983
@@ -476,6 +512,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     if (!stop) { b_inner++; if (b_inner >= depth_inner) stop = true; }
                     if (stop) {
                         if (!have_L) L = B.ld3(SF_L, slot);
+                        if (MODE == 2) { const double luma = 0.2126 * len(L); if (luma > 2.0) L = L * (2.0 / luma); }
                         contrib = B.ld3(SF_ATT0, slot) * L; ended = true;
                     } else {
                         if (have_L) B.st3(SF_L, slot, L);
@@ -496,11 +533,19 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 // radiance of this sample = L0 + att0 * L (camera.hpp:1000), written exactly once
                 V3 rad = contrib;
                 if (has_add) rad = add_now + rad;
-                else if (!first && (m.y & F_L0)) rad = B.ld3(SF_SUM, slot) + rad;
-                const uint32_t unit = B.ld2(SF_MB, slot).x;
-                double* pp = B.samples + (size_t)unit * 3;
-                pp[0] = rad.x; pp[1] = rad.y; pp[2] = rad.z;
-                if (COUNT) c_draws += g.k;
+                else if (MODE != 2 && !first && (m.y & F_L0)) rad = B.ld3(SF_SUM, slot) + rad;
+                const uint2 mb = B.ld2(SF_MB, slot);
+                const uint32_t unit = mb.x;
+                if (MODE != 2 || !no_output) {
+                    double* pp = B.samples + (size_t)unit * 3;
+                    pp[0] = rad.x; pp[1] = rad.y; pp[2] = rad.z;
+                }
+                if (MODE == 1) { uint2 ke; ke.x = (uint32_t)g.k; ke.y = g.bounce; B.kend[unit] = ke; }
+                if (MODE == 2 && !no_output) B.cls[unit] = (unsigned char)mb.y;
+                if (COUNT) {
+                    if (MODE != 2) c_draws += g.k;
+                    else if (!(first && ki.x == NONE)) c_draws += g.k - B.kend[unit].x;   // draws of the second path only
+                }
                 want_unit = true;
             }
         }
@@ -526,9 +571,17 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     // ~3 ms per 16 M-slot round (262 144 wave atomics at ~90 per microsecond)
     const unsigned long long am = __ballot(active_after);
     if ((threadIdx.x & 63) == 0 && am != 0ull) atomicAdd(&B.ctl[16 + 32 * (blockIdx.x % ST_SHARDS) + 16], (unsigned int)__popcll(am));
-    if (COUNT) {
+    if (COUNT && MODE == 0) {
         if (c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
         if (c_draws) atomicAdd(&gctr[8], c_draws);
+    }
+    if (MODE != 0) {
+        if (c_samp) atomicAdd(&s_cnt[0], (unsigned long long)c_samp);
+        if (c_seg2) atomicAdd(&s_cnt[1], (unsigned long long)c_seg2);
+        if (c_hit2) atomicAdd(&s_cnt[2], (unsigned long long)c_hit2);
+        if (c_draws) atomicAdd(&s_cnt[3], c_draws);
+        __syncthreads();
+        if (threadIdx.x < 4 && s_cnt[threadIdx.x]) B.cpart[(size_t)blockIdx.x * 4 + threadIdx.x] += s_cnt[threadIdx.x];
     }
 }
 
@@ -552,6 +605,43 @@ __global__ __launch_bounds__(256) void stream_reduce(StreamBuf B, DCamera cam, d
         const double scale = 1.0 / cam.spp;  // camera.hpp:437,531
         double* o = out + ((size_t)py * cam.W + px) * 3;
         o[0] = sx * scale; o[1] = sy * scale; o[2] = sz * scale;
+    }
+}
+
+// per-block counters of the split passes -> the context's counter words (samples, segments, hits, draws)
+__global__ __launch_bounds__(256) void stream_sum_counters(const unsigned long long* __restrict__ cpart, size_t n_blocks, unsigned long long* __restrict__ gctr) {
+    __shared__ unsigned long long s[4];
+    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long a[4] = {0, 0, 0, 0};
+    for (size_t b = threadIdx.x; b < n_blocks; b += 256) for (int k = 0; k < 4; k++) a[k] += cpart[b * 4 + k];
+    for (int k = 0; k < 4; k++) if (a[k]) atomicAdd(&s[k], a[k]);
+    __syncthreads();
+    if (threadIdx.x == 0) { gctr[0] += s[0]; gctr[1] += s[1]; gctr[7] += s[2]; gctr[8] += s[3]; }
+}
+
+// the split frames: the same order-fixed sum, every sample to the frame its class names
+__global__ __launch_bounds__(256) void stream_reduce_split(StreamBuf B, DCamera cam, double* __restrict__ out_reflection, double* __restrict__ out_refraction) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= B.n_pix) return;
+    const double* pp = B.samples + (size_t)i * B.spp * 3;
+    const unsigned char* cc = B.cls + (size_t)i * B.spp;
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t sidx = (uint32_t)lane; sidx < B.spp; sidx += 64) {
+        const unsigned char c = cc[sidx];
+        if (c == 1) { a[0] += pp[sidx * 3]; a[1] += pp[sidx * 3 + 1]; a[2] += pp[sidx * 3 + 2]; }
+        else if (c == 2) { a[3] += pp[sidx * 3]; a[4] += pp[sidx * 3 + 1]; a[5] += pp[sidx * 3 + 2]; }
+    }
+    for (int m = 32; m >= 1; m >>= 1)
+        for (int k = 0; k < 6; k++) a[k] += __hiloint2double(__shfl_xor(__double2hiint(a[k]), m, 64), __shfl_xor(__double2loint(a[k]), m, 64));
+    if (lane == 0) {
+        const uint32_t pk = B.pixels[i];
+        const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
+        const double scale = 1.0 / cam.spp;  // camera.hpp:532-533
+        const size_t o = ((size_t)py * cam.W + px) * 3;
+        if (out_reflection) { out_reflection[o] = a[0] * scale; out_reflection[o + 1] = a[1] * scale; out_reflection[o + 2] = a[2] * scale; }
+        if (out_refraction) { out_refraction[o] = a[3] * scale; out_refraction[o + 1] = a[4] * scale; out_refraction[o + 2] = a[5] * scale; }
     }
 }
 
@@ -614,7 +704,7 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
                           unsigned int* ctl, unsigned int* uctl, uint32_t unit0, uint32_t unit_base) {
     StreamBuf B;
     B.pool = (double*)pool; B.pixels = pixels; B.samples = samples; B.ctl = ctl; B.uctl = uctl;
-    B.P = P; B.spp = spp; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base;
+    B.P = P; B.spp = spp; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base; B.kend = nullptr; B.cls = nullptr; B.cpart = nullptr;
     return B;
 }
 
@@ -631,7 +721,8 @@ static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, 
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic) {
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode, void* d_kend, void* d_cls,
+                         double* out2, unsigned long long* d_cpart) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     int K = n_pools < 1 ? 1 : (n_pools > ST_MAX_POOLS ? ST_MAX_POOLS : n_pools);
@@ -645,6 +736,8 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         for (int k = 0; k < K; k++) {
             uint32_t Pk = k == K - 1 ? P - first : (P / K + 63) / 64 * 64;
             Q[k] = make_buf(base, Pk, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + (size_t)k * W, uctl, first, P);
+            Q[k].kend = (uint2*)d_kend; Q[k].cls = (unsigned char*)d_cls;
+            Q[k].cpart = d_cpart ? d_cpart + ((size_t)first / 256 + (size_t)k) * 4 : nullptr;
             ov[k] = (unsigned char*)d_overflow + (size_t)k * stream_overflow_bytes(extend_blocks);
             base += stream_pool_bytes(Pk);
             first += Pk;
@@ -653,6 +746,8 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     hipError_t e;
     hipStream_t stream = streams[0];
     if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    const size_t cpart_blocks = (size_t)P / 256 + ST_MAX_POOLS + 1;
+    if (d_cpart && (e = hipMemsetAsync(d_cpart, 0, cpart_blocks * 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     auto init = [&](const StreamBuf& B, hipStream_t st) {
         if (timer) timer->begin(st, 0);
         if (count) hipLaunchKernelGGL(stream_init<true>, dim3((B.P + 255) / 256), dim3(256), 0, st, B, cam, seed, gctr);
@@ -667,8 +762,11 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     };
     auto shade = [&](const StreamBuf& B, hipStream_t st) {
         if (timer) timer->begin(st, 2);
-        if (count) hipLaunchKernelGGL(stream_shade<true>, dim3((B.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, B, gctr);
-        else hipLaunchKernelGGL(stream_shade<false>, dim3((B.P + 255) / 256), dim3(256), 0, st, sc, cam, env, seed, B, gctr);
+        const dim3 sg((B.P + 255) / 256), sb(256);
+        if (mode == 1) hipLaunchKernelGGL((stream_shade<true, 1>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);        // the split passes always count
+        else if (mode == 2) hipLaunchKernelGGL((stream_shade<true, 2>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
+        else if (count) hipLaunchKernelGGL((stream_shade<true, 0>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
+        else hipLaunchKernelGGL((stream_shade<false, 0>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
         if (timer) timer->end(st, 2);
     };
     // start-up: pool k is initialised after the control words are cleared and starts once pool k-1 has a round in flight
@@ -704,7 +802,9 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     for (int k = 0; k < K; k++) if (h_active[(size_t)k * W + 2] != 0) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
     const StreamBuf& A = Q[0];
     if (timer) timer->begin(stream, 3);
-    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
+    if (d_cpart) hipLaunchKernelGGL(stream_sum_counters, dim3(1), dim3(256), 0, stream, d_cpart, cpart_blocks, gctr);
+    if (mode == 2) hipLaunchKernelGGL(stream_reduce_split, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out, out2);
+    else if (out) hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
     if (rounds_out) *rounds_out = cancelled ? -rounds : rounds;
     return hipGetLastError();
