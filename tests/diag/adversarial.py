@@ -1,4 +1,4 @@
-"""Development aid (GPU): which adversarial ray classes make an engine disagree with the oracle?"""
+"""Parity debugging aid, part of the test infrastructure (GPU): which adversarial ray classes make an engine disagree with the oracle?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

@@ -1,4 +1,4 @@
-"""Development aid (GPU): where does a scene differ from the oracle?  Bisects over max_depth and spp."""
+"""Parity debugging aid, part of the test infrastructure (GPU): where does a scene differ from the oracle?  Bisects over max_depth and spp."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

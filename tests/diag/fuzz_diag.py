@@ -1,4 +1,4 @@
-"""Development aid (GPU): details of the rays on which a fuzz scene (tests/test_fuzz_scenes.py) disagrees with the oracle."""
+"""Parity debugging aid, part of the test infrastructure (GPU): details of the rays on which a fuzz scene (tests/test_fuzz_scenes.py) disagrees with the oracle."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,4 +1,4 @@
-"""Development aid (GPU): first segment at which the device and the oracle disagree, for all samples of some pixels."""
+"""Parity debugging aid, part of the test infrastructure (GPU): first segment at which the device and the oracle disagree, for all samples of some pixels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

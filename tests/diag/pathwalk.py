@@ -1,4 +1,4 @@
-"""Development aid (GPU): walk paths on the oracle and compare every segment's hit record with the GPU's zr_trace."""
+"""Parity debugging aid, part of the test infrastructure (GPU): walk paths on the oracle and compare every segment's hit record with the GPU's zr_trace."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
