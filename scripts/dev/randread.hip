@@ -22,12 +22,12 @@ __global__ __launch_bounds__(64, 6) void chase(const float4* __restrict__ a, uin
     if (acc == 123.456f) out[0] = x;
 }
 int main() {
-    const size_t sizes[] = {(size_t)1 << 20, (size_t)3 << 20, (size_t)16 << 20, (size_t)64 << 20};
+    const size_t sizes[] = {(size_t)1 << 20, (size_t)3 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)1 << 30};
     uint32_t* out; hipMalloc(&out, 4);
     for (size_t bytes : sizes) {
         float4* a; hipMalloc(&a, bytes); hipMemset(a, 0, bytes);
-        for (int active : {64, 16}) {
-            for (int rec : {64, 128}) {
+        for (int active : {64}) {
+            for (int rec : {32, 64, 128}) {
                 const int blocks = 256 * 24, iters = 2000;
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 for (int rep = 0; rep < 2; rep++) {
