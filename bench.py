@@ -156,7 +156,8 @@ def main():
         try:  # HBM bytes per launch of the dominant kernel from the committed FETCH_SIZE pass (separate --pmc run)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1_v2f_cfg3_traffic.json")))
             if tj["workload"] == args.workload and world == 1 and args.spp == 0:
-                traffic = int(tj["kernels"][kernel_name]["hbm_read_bytes_per_launch"])
+                kj = tj["kernels"][kernel_name]
+                traffic = int(kj["hbm_read_bytes_per_launch"] + kj.get("hbm_write_bytes_per_launch", 0))   # reads (x2 corrected) + writes
         except Exception:
             traffic = None
         out = {
