@@ -50,7 +50,8 @@ namespace zr {
 #endif
 #define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
-enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18 };  // meta.y: bounce | b_inner << 8 | flags (F_L0: SF_SUM holds the primary hit's emission)
+enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18,
+       F_LZERO = 1u << 19 /* SF_L not written yet: it is (0,0,0) */, F_BONE = 1u << 20 /* SF_BETA not written yet: it is (1,1,1) */ };  // meta.y: bounce | b_inner << 8 | flags (F_L0: SF_SUM holds the primary hit's emission)
 
 struct SEntry { uint32_t node; float tn; };
 
@@ -441,6 +442,11 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             int b_inner = (int)((m.y >> 8) & 0xFFu);
             const bool first = (m.y & F_FIRST) != 0;
             const int depth_inner = cam.max_depth - 1;
+            // after the first hit L = 0 and beta = 1 (camera.hpp:930): both stay implicit (two flag bits) until something else is
+            // stored, which saves their 48 bytes written and read back per path; the values used are the same (0 + x, 1 * x)
+            auto load_L = [&]() { return (m.y & F_LZERO) ? mk(0, 0, 0) : B.ld3(SF_L, slot); };
+            auto load_beta = [&]() { return (m.y & F_BONE) ? mk(1, 1, 1) : B.ld3(SF_BETA, slot); };
+            uint32_t keep_lzero = m.y & F_LZERO;
             // the split passes count segments and hits here (SHADE sees every segment exactly once), so that their EXTEND can be
             // the uninstrumented build; the replay's first segment is the beauty pass's, found again: not counted
             if (COUNT && MODE != 0 && !(MODE == 2 && first)) { c_seg2++; if (ki.x != 0xFFFFFFFFu) c_hit2++; }
@@ -455,12 +461,12 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 else {
                     V3 bg = background(sc, env, ray.d);
                     if (MODE == 2) {
-                        V3 scol = B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg;
+                        V3 scol = load_L() + load_beta() * bg;
                         const double luma = 0.2126 * len(scol);                  // camera.hpp:499-503
                         if (luma > 2.0) scol = scol * (2.0 / luma);
                         contrib = B.ld3(SF_ATT0, slot) * scol;
                     } else {
-                        contrib = first ? bg : B.ld3(SF_ATT0, slot) * (B.ld3(SF_L, slot) + B.ld3(SF_BETA, slot) * bg);  // camera.hpp:520 / 941,1000
+                        contrib = first ? bg : B.ld3(SF_ATT0, slot) * (load_L() + load_beta() * bg);  // camera.hpp:520 / 941,1000
                     }
                     ended = true;
                 }
@@ -488,15 +494,15 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     if (MODE != 2 && has_em) { add_now = em; has_add = true; }
                     if (!sc_ok || depth_inner <= 0) { ended = true; if (MODE == 2) no_output = true; }
                     else {
-                        B.st3(SF_ATT0, slot, att); B.st3(SF_L, slot, mk(0, 0, 0)); B.st3(SF_BETA, slot, mk(1, 1, 1));
+                        B.st3(SF_ATT0, slot, att);   // L = 0, beta = 1: implicit (F_LZERO | F_BONE below)
                         if (MODE == 2) { uint2 mb = B.ld2(SF_MB, slot); mb.y = cls_now; B.st2(SF_MB, slot, mb); }
                         b_inner = 0;
                     }
                 } else {      // body of ray_color's loop, camera.hpp:944-983
-                    V3 beta = B.ld3(SF_BETA, slot);
+                    V3 beta = load_beta();
                     V3 L = mk(0, 0, 0);
                     bool have_L = false;
-                    if (has_em) { L = B.ld3(SF_L, slot) + beta * em; have_L = true; }
+                    if (has_em) { L = load_L() + beta * em; have_L = true; }
                     bool stop = !sc_ok;
                     if (!stop) {
                         beta = beta * att;
@@ -511,11 +517,11 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     }
                     if (!stop) { b_inner++; if (b_inner >= depth_inner) stop = true; }
                     if (stop) {
-                        if (!have_L) L = B.ld3(SF_L, slot);
+                        if (!have_L) L = load_L();
                         if (MODE == 2) { const double luma = 0.2126 * len(L); if (luma > 2.0) L = L * (2.0 / luma); }
                         contrib = B.ld3(SF_ATT0, slot) * L; ended = true;
                     } else {
-                        if (have_L) B.st3(SF_L, slot, L);
+                        if (have_L) { B.st3(SF_L, slot, L); keep_lzero = 0; }
                         B.st3(SF_BETA, slot, beta);
                     }
                 }
@@ -524,7 +530,8 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     B.st3(SF_RAY, slot, nr.o); B.st3(SF_RAY + 3, slot, nr.d);
                     if (has_add) B.st3(SF_SUM, slot, add_now);
                     m.x = (uint32_t)g.k;
-                    m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE | (first ? (has_add ? F_L0 : 0u) : (m.y & F_L0));
+                    m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE | (first ? (has_add ? F_L0 : 0u) : (m.y & F_L0)) |
+                          (first ? (F_LZERO | F_BONE) : keep_lzero);
                     B.st2(SF_MA, slot, m);
                     active_after = true;
                 }
