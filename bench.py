@@ -154,7 +154,7 @@ def main():
         achieved = (bytes_local / launches_per_step) / (k_ms * 1e-3) * 1e-9 if k_ms > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel from the committed FETCH_SIZE pass (separate --pmc run)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_v2f_cfg3_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_v2g_cfg3_traffic.json")))
             if tj["workload"] == args.workload and world == 1 and args.spp == 0:
                 kj = tj["kernels"][kernel_name]
                 traffic = int(kj["hbm_read_bytes_per_launch"] + kj.get("hbm_write_bytes_per_launch", 0))   # reads (x2 corrected) + writes
