@@ -9,12 +9,11 @@
 //   texture::value     texture.hpp:50-78,96-98,118-126
 //   random_double() and the rejection samplers  common.hpp:29-44  vec3.hpp:174-191
 //
-// What is NOT the genuine code: camera.hpp cannot be compiled in this image — it includes
-// <OpenImageDenoise/oidn.hpp> (camera.hpp:10), a library that is absent — so the camera set-up, the ray
-// generator, the background and the bounce loop are RESTATED below (struct ref_camera), following
-// camera.hpp:358-402 (initialize), 784-825 (get_ray), 828-925 (get_background_color),
-// 928-986 (ray_color), 989-1004 (ray_color_from_hit) and the beauty part of render_rows 454-531,
-// on the reference's own vec3/ray/hittable/material/EnvironmentSettings types.
+// camera.hpp cannot be #included in this image — it includes <OpenImageDenoise/oidn.hpp> (camera.hpp:10), a library
+// that is absent, and no stand-in header is written for it.  Its hot-path MEMBER FUNCTIONS are nevertheless the genuine
+// ones: oracle/Makefile cuts their text out of camera.hpp at build time and class ref_camera below includes it (see
+// there).  Only the body of the per-sample loop of render_rows (camera.hpp:454-531, a lambda that cannot be cut out)
+// is restated, in ref_camera::sample / aov_sample / passes_sample.
 //
 // Determinism: ref_prelude.hpp injects the counter engine of include/zr_rng.h in place of the
 // reference's racy global mt19937.  Build with ROCm clang++ (left-to-right argument evaluation, the
@@ -92,137 +91,43 @@ private:
     const hittable& w;
 };
 
-// ---- restated camera (see header comment) ------------------------------------------------------
-struct ref_camera {
-    zr_camera c;
-    point3 center, pixel00;
-    vec3 du, dv, u, v, w, disk_u, disk_v;
+// ---- the reference's camera member functions, compiled from camera.hpp itself ------------------------------
+// camera.hpp cannot be #included (OpenImageDenoise, line 10).  oracle/Makefile therefore cuts the TEXT of the member
+// functions on the hot path out of /root/reference/camera.hpp at build time — initialize() (camera.hpp:358-399, i.e.
+// without its last statement, the refresh_hdr_list() directory scan of line 401) and get_ray ... ray_color_from_hit
+// (camera.hpp:784-1004) — into a scratch file outside the repo (zr_ref_camera_members.inc in a mktemp directory that
+// the recipe deletes after the compile: reference text is neither committed nor shipped to the GPU box) and this
+// scaffold class, which declares nothing but the data members those functions read (names and defaults as
+// camera.hpp:26-44,341-349), includes it.  So initialize / get_ray / sample_square / defocus_disk_sample /
+// get_background_color / ray_color / ray_color_from_hit below are the GENUINE functions, not restatements.
+class ref_camera {
+public:
+    double aspect_ratio = 1.0;
+    int image_width = 400, image_height = 225, samples_per_pixel = 30, max_depth = 10;
+    double vfov = 30;
+    point3 lookfrom = point3(10, 1.5, 0), lookat = point3(0, 0, 0);
+    vec3 vup = vec3(0, 1, 0);
+    double defocus_angle = 0.5, focus_dist = 10;
+    double pixel_samples_scale = 0.0;
+    point3 center, pixel00_loc;
+    vec3 pixel_delta_u, pixel_delta_v, u, v, w, defocus_disk_u, defocus_disk_v;
 
-    void initialize() {  // camera.hpp:358-399
-        if (c.image_width < 1) c.image_width = 1;
-        if (c.image_height < 1) c.image_height = 1;
-        double aspect = double(c.image_width) / c.image_height;
-        center = point3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
-        point3 at(c.lookat[0], c.lookat[1], c.lookat[2]);
-        vec3 up(c.vup[0], c.vup[1], c.vup[2]);
-        double theta = degrees_to_radians(c.vfov);
-        double h = std::tan(theta / 2);
-        double vh = 2 * h * c.focus_dist;
-        double vw = vh * aspect;
-        w = unit_vector(center - at);
-        u = unit_vector(cross(up, w));
-        v = cross(w, u);
-        vec3 vu = vw * u;
-        vec3 vv = vh * -v;
-        du = vu / c.image_width;
-        dv = vv / c.image_height;
-        point3 ul = center - (c.focus_dist * w) - vu / 2 - vv / 2;
-        pixel00 = ul + 0.5 * (du + dv);
-        double rad = c.focus_dist * std::tan(degrees_to_radians(c.defocus_angle / 2));
-        disk_u = u * rad;
-        disk_v = v * rad;
+#include "zr_ref_camera_members.inc"
+
+    // ---- harness side: everything below is the oracle's own code -------------------------------------------
+    zr_camera c{};
+    void setup() {   // C-ABI camera description -> the reference's public fields, then the genuine initialize()
+        image_width = c.image_width; image_height = c.image_height; samples_per_pixel = c.samples_per_pixel; max_depth = c.max_depth;
+        vfov = c.vfov;
+        lookfrom = point3(c.lookfrom[0], c.lookfrom[1], c.lookfrom[2]);
+        lookat = point3(c.lookat[0], c.lookat[1], c.lookat[2]);
+        vup = vec3(c.vup[0], c.vup[1], c.vup[2]);
+        defocus_angle = c.defocus_angle; focus_dist = c.focus_dist;
+        initialize();
     }
 
-    ray get_ray(int i, int j) const {  // camera.hpp:784-794, 817-825
-        double ox = random_double() - 0.5;  // sample_square: x drawn first (left-to-right build)
-        double oy = random_double() - 0.5;
-        point3 ps = pixel00 + ((i + ox) * du) + ((j + oy) * dv);
-        point3 org = center;
-        if (!(c.defocus_angle <= 0)) {
-            vec3 p = random_in_unit_disk();
-            org = center + (p[0] * disk_u) + (p[1] * disk_v);
-        }
-        return ray(org, ps - org);
-    }
-
-    color background(const ray& r, const EnvironmentSettings& env) const {  // camera.hpp:828-925
-        vec3 ud = unit_vector(r.direction());
-        if (env._mode == EnvironmentSettings::SOLID_COLOR) return env.background_color * env.intensity;
-        if (env._mode == EnvironmentSettings::HDR_MAP) {
-            if (!env.hdr_texture) return color(0, 0, 0);
-            vec3 d = ud;
-            double cy = cos(env.hdri_rotation), sy = sin(env.hdri_rotation);
-            double x1 = cy * d.x() + sy * d.z();
-            double z1 = -sy * d.x() + cy * d.z();
-            d = vec3(x1, d.y(), z1);
-            double cp = cos(env.hdri_tilt), sp = sin(env.hdri_tilt);
-            double y2 = cp * d.y() - sp * d.z();
-            double z2 = sp * d.y() + cp * d.z();
-            d = vec3(d.x(), y2, z2);
-            double cr = cos(env.hdri_roll), sr = sin(env.hdri_roll);
-            double x3 = cr * d.x() - sr * d.y();
-            double y3 = sr * d.x() + cr * d.y();
-            d = vec3(x3, y3, d.z());
-            double phi = atan2(d.z(), d.x()) + pi;
-            double theta = acos(std::clamp(d.y(), -1.0, 1.0));
-            return env.hdr_texture->value(phi / (2 * pi), theta / pi, point3(0, 0, 0)) * env.intensity;
-        }
-        vec3 sun = unit_vector(env.sun_direction);
-        double sh = sun.y();
-        double ah = sh - 0.05;
-        double sky_exposure = std::clamp(ah * 8.0 + 1.4, 0.0, 1.0);
-        double day = std::clamp(ah * 10.0 + 1.1, 0.0, 1.0);
-        double sunset_i = std::clamp(1.0 - std::abs(ah + 0.05) * 30.0, 0.0, 1.0);
-        double sunset = (ah > -0.1) ? sunset_i : 0.0;
-        if (sh < 0) sunset *= (sh * 10.0 + 1.0);
-        sunset = std::clamp(sunset, 0.0, 1.0);
-        color zen = color(0.01, 0.03, 0.1) * (1.0 - day) + color(0.2, 0.5, 1.0) * day;
-        color hor = color(0.05, 0.02, 0.01) * (1.0 - day) + color(0.6, 0.8, 1.0) * day;
-        hor = hor * (1.0 - sunset) + color(1.0, 0.35, 0.1) * sunset;
-        double a = ud.y();
-        color sky;
-        if (a > 0.0) sky = (1.0 - a) * hor + a * zen; else sky = hor * 0.1;
-        color fin = sky * (env.intensity * 1.5) * sky_exposure;
-        double focus = dot(ud, sun);
-        double thr = 1.0 - (env.sun_size * 0.001);
-        if (focus > thr && ah > -0.1) {
-            color sc = env.sun_color * (1.0 - sunset) + color(1.0, 0.3, 0.1) * sunset;
-            double vis = std::clamp(sh * 5.0 + 1.0, 0.0, 1.0);
-            double alpha = smoothstep(thr, thr + 0.0002, focus);
-            fin += sc * env.sun_intensity * vis * alpha;
-        }
-        return fin;
-    }
-
-    color ray_color(const ray& r, const hittable& world, int depth, const EnvironmentSettings& env) const {
-        // camera.hpp:928-986 (bvh_debug_mode branches are out of scope)
-        color L(0, 0, 0), beta(1, 1, 1);
-        ray cur = r;
-        for (int i = 0; i < depth; i++) {
-            hit_record rec;
-            if (!world.hit(cur, interval(0.001, infinity), rec, 0, false)) return L + beta * background(cur, env);
-            color em = rec.mat->emitted(rec.u, rec.v, rec.p);
-            L += beta * em;
-            ray sc; color att;
-            if (rec.mat->scatter(cur, rec, att, sc)) {
-                beta *= att;
-                cur = sc;
-                if (i > 10 && beta.length() < 0.0001) break;
-            } else {
-                break;
-            }
-            if (i > 10) {
-                double p = std::max({beta.x(), beta.y(), beta.z()});
-                p = std::clamp(p, 0.05, 0.95);
-                if (random_double() > p) break;
-                beta /= p;
-            }
-        }
-        return L;
-    }
-
-    color ray_color_from_hit(const ray& r, const hit_record& first, const hittable& world, int depth,
-                             const EnvironmentSettings& env) const {  // camera.hpp:989-1004
-        color L = first.mat->emitted(first.u, first.v, first.p);
-        color beta(1, 1, 1);
-        ray sc; color att;
-        if (first.mat->scatter(r, first, att, sc)) {
-            beta *= att;
-            return L + beta * ray_color(sc, world, depth - 1, env);
-        }
-        return L;
-    }
-
+    // The three functions below restate the BODY of the per-sample loop of render_rows (camera.hpp:454-531), which is a
+    // lambda inside execute_render_threads and cannot be cut out: every call they make is to genuine code.
     // first-hit AOVs of one primary sample: camera.hpp:464-488 (hit) and 521-525 (miss)
     void aov_sample(int i, int j, const hittable& world, double zmax, color& albedo, color& normal, color& zdepth) const {
         ray r = get_ray(i, j);
@@ -246,11 +151,11 @@ struct ref_camera {
         ray r = get_ray(i, j);
         hit_record rec;
         if (world.hit(r, interval(0.001, infinity), rec)) {
-            beauty += ray_color_from_hit(r, rec, world, c.max_depth, env);
+            beauty += ray_color_from_hit(r, rec, world, max_depth, env);
             ray scattered;
             color attenuation;
             if (rec.mat->scatter(r, rec, attenuation, scattered)) {
-                color scattered_color = ray_color(scattered, world, c.max_depth - 1, env);
+                color scattered_color = ray_color(scattered, world, max_depth - 1, env);
                 double luma = 0.2126 * scattered_color.length();
                 double max_luma = 2.0;
                 if (luma > max_luma) scattered_color *= (max_luma / luma);
@@ -260,7 +165,7 @@ struct ref_camera {
                 else if (dot(scattered.direction(), rec.normal) < 0) refraction += attenuation * scattered_color;
             }
         } else {
-            beauty += background(r, env);
+            beauty += get_background_color(r, env);
         }
     }
 
@@ -268,8 +173,8 @@ struct ref_camera {
     color sample(int i, int j, const hittable& world, const EnvironmentSettings& env) const {
         ray r = get_ray(i, j);
         hit_record rec;
-        if (world.hit(r, interval(0.001, infinity), rec)) return ray_color_from_hit(r, rec, world, c.max_depth, env);
-        return background(r, env);
+        if (world.hit(r, interval(0.001, infinity), rec)) return ray_color_from_hit(r, rec, world, max_depth, env);
+        return get_background_color(r, env);
     }
 };
 
@@ -324,7 +229,7 @@ static tile_result render_tile(const built_scene& b, ref_camera cam, int x0, int
                                int xstep, int ystep, std::vector<double>& mean, std::vector<double>* per_sample,
                                std::vector<uint32_t>* per_sample_counts) {
     cam.c.samples_per_pixel = spp;
-    cam.initialize();
+    cam.setup();
     const int W = cam.c.image_width;
     mean.assign((size_t)w * h * 3, 0.0);
     if (per_sample) per_sample->assign((size_t)w * h * spp * 3, 0.0);
@@ -423,7 +328,7 @@ int main(int argc, char** argv) {
         int x0 = iarg(3, 0), y0 = iarg(4, 0), w = iarg(5, 1), h = iarg(6, 1);
         double zmax = std::atof(argv[7]);
         std::string out = argv[8];
-        ref_camera cam; cam.c = b.s.cam; cam.initialize();
+        ref_camera cam; cam.c = b.s.cam; cam.setup();
         const int spp = cam.c.samples_per_pixel;
         const int aux_sample = std::clamp(spp / 8, 64, 1024);   // camera.hpp:433
         const int actual = std::min(aux_sample, spp);            // camera.hpp:535
@@ -464,7 +369,7 @@ int main(int argc, char** argv) {
         std::string out = argv[8];
         ref_camera cam; cam.c = b.s.cam;
         if (spp > 0) cam.c.samples_per_pixel = spp;
-        cam.initialize();
+        cam.setup();
         spp = cam.c.samples_per_pixel;
         probe_world world(*b.bvh);
         std::vector<double> B((size_t)w * h * 3), R((size_t)w * h * 3), F((size_t)w * h * 3);

@@ -135,3 +135,25 @@ def test_oracle_matches_reference_passes(name, built):
     # the beauty frame of the split render is the plain render (same stream prefix)
     plain, _, _, _ = zo.OracleScene(ds.desc).render(cam, ds.env, ds.seed, reg)
     assert np.array_equal(plain[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]], b)
+
+
+def test_reference_binary_reproduces_fixture(built, tmp_path):
+    """oracle/_ref/zenith_ref as built NOW (camera::initialize / get_ray / get_background_color / ray_color /
+    ray_color_from_hit compiled from the text of the reference's camera.hpp, oracle/Makefile) must reproduce the committed
+    fixtures bit for bit: ties the fixtures to the genuine camera functions, not to an earlier restatement."""
+    import json
+    import subprocess
+    from oracle import zr_oracle_py as zo
+    if not zo.ref_available():
+        pytest.skip("oracle/_ref/zenith_ref not built (needs /root/reference)")
+    for name in ("cfg1_tile", "mix1_full"):   # PHYSICAL_SUN pinhole; HDR_MAP yaw/tilt/roll + thin lens
+        fx = load_golden(name)
+        m = fx["meta"]
+        pre = str(tmp_path / name)
+        p = subprocess.run([zo.REF_BIN, "tile", m["scene"], str(m["x0"]), str(m["y0"]), str(m["w"]), str(m["h"]), str(m["spp"]), "2", pre,
+                            "1" if "samples" in fx else "0"] + [str(a) for a in m["scene_args"]], capture_output=True, text=True, check=True)
+        got = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert (got["segments"], got["draws"]) == (m["segments"], m["draws"])
+        assert np.array_equal(np.load(pre + "_mean.npy"), fx["mean"])
+        if "samples" in fx:
+            assert np.array_equal(np.load(pre + "_samples.npy"), fx["samples"])
