@@ -11,8 +11,10 @@
 //   * camera::render() does not run a CPU loop: it flattens the world into the arrays of
 //     include/zr_capi.h and calls the C ABI (libzr_hip.so); if that library or a HIP device is
 //     missing it reports the error on std::cerr and leaves the buffers zeroed — there is NO CPU fallback;
-//   * hittable::hit()/material::scatter() of the built-in classes are not CPU-evaluated here (they
-//     throw std::logic_error): the per-ray virtual path is exactly what this drop-in replaces;
+//   * hittable::hit() / material::scatter() of the built-in classes stay CALLABLE, but they are not CPU-evaluated: a
+//     call flattens the object (cached in the object), commits it as a one-object device scene and sends the ray
+//     through the same kernels the renderer uses (zr_trace / zr_kat_scatter of the C ABI).  One launch per call — the
+//     per-ray virtual path is exactly what this drop-in replaces, so this is for probing and tests, never for rendering;
 //   * random_double() draws from the seedable contract stream of include/zr_rng.h instead of a racy
 //     process-global mt19937 (common.hpp:29-34).
 // No code is taken from the reference; each class cites the interface it mirrors.
@@ -244,6 +246,9 @@ private:
     bool captured_ok = false;
     std::unordered_map<const material*, uint32_t> mat_ids;
     std::unordered_map<const texture*, uint32_t> tex_ids;
+public:
+    std::unordered_map<uint32_t, shared_ptr<material>> mat_ptrs;   // flattened material id -> the object it came from
+private:
 
     uint32_t copy_chain(size_t from, size_t to) {
         uint32_t first = (uint32_t)fs.ops.size();
@@ -269,6 +274,13 @@ private:
     throw std::logic_error(std::string(what) + ": the MI355X drop-in does not evaluate rays on the CPU; render through camera::render()");
 }
 
+// hittable::hit / material::scatter of the built-in classes, answered by the device (defined at the end of this header)
+struct device_object;
+}  // namespace zenith
+class hit_record;
+namespace zenith {
+bool device_hit(const hittable& self, const ray& r, const interval& ray_t, hit_record& rec);
+bool device_scatter(const material& self, const ray& r_in, const hit_record& rec, vec3& attenuation, ray& scattered);
 }  // namespace zenith
 
 // ---- hittable.hpp ---------------------------------------------------------------------------------
@@ -292,6 +304,7 @@ public:
     // drop-in extension: hand the object's data to the device backend.  User-defined hittables that do
     // not override it are reported and skipped.
     virtual void flatten(zenith::scene_builder& b) const { b.unsupported(typeid(*this).name()); }
+    mutable shared_ptr<zenith::device_object> zr_device_cache_;   // drop-in: the committed one-object scene hit() sends rays to
 };
 
 // ---- texture.hpp ----------------------------------------------------------------------------------
@@ -439,6 +452,7 @@ public:
     virtual bool scatter(const ray& r_in, const hit_record& rec, color& attenuation, ray& scattered) const = 0;
     virtual color get_albedo(const hit_record&) const { return color(0, 0, 0); }
     virtual uint32_t flatten(zenith::scene_builder& b) const = 0;
+    mutable shared_ptr<zenith::device_object> zr_device_cache_;   // drop-in: the committed scene scatter() runs on
 };
 
 class lambertian : public material {
@@ -446,7 +460,7 @@ public:
     lambertian(const color& albedo, shared_ptr<texture> bump = nullptr, double strength = 1.0)
         : tex(make_shared<solid_color>(albedo)), bump(bump), strength(strength) {}
     lambertian(shared_ptr<texture> tex, shared_ptr<texture> bump = nullptr, double strength = 1.0) : tex(tex), bump(bump), strength(strength) {}
-    bool scatter(const ray&, const hit_record&, color&, ray&) const override { zenith::no_cpu_path("lambertian::scatter"); }
+    bool scatter(const ray& r_in, const hit_record& rec, color& attenuation, ray& scattered) const override { return zenith::device_scatter(*this, r_in, rec, attenuation, scattered); }
     color get_albedo(const hit_record& rec) const override { return tex->value(rec.u, rec.v, rec.p); }
     uint32_t flatten(zenith::scene_builder& b) const override {
         zr_material m{}; m.kind = ZR_MAT_LAMBERTIAN; m.tex = b.texture_id(tex); m.bump_tex = b.texture_id(bump); m.bump_strength = strength;
@@ -462,7 +476,7 @@ public:
         : albedo(a), fuzz(f < 1 ? f : 1), bump(bump), strength(strength) {}
     metal(const color& a, double f, shared_ptr<texture> bump = nullptr, double strength = 1.0)
         : albedo(make_shared<solid_color>(a)), fuzz(f < 1 ? f : 1), bump(bump), strength(strength) {}
-    bool scatter(const ray&, const hit_record&, color&, ray&) const override { zenith::no_cpu_path("metal::scatter"); }
+    bool scatter(const ray& r_in, const hit_record& rec, color& attenuation, ray& scattered) const override { return zenith::device_scatter(*this, r_in, rec, attenuation, scattered); }
     color get_albedo(const hit_record& rec) const override { return albedo->value(rec.u, rec.v, rec.p); }
     uint32_t flatten(zenith::scene_builder& b) const override {
         zr_material m{}; m.kind = ZR_MAT_METAL; m.tex = b.texture_id(albedo); m.bump_tex = b.texture_id(bump); m.bump_strength = strength; m.param = fuzz;
@@ -477,7 +491,7 @@ public:
     dielectric(double ri, const color& a = color(1.0, 1.0, 1.0)) : ri(ri), albedo(a), bump(nullptr), strength(1.0) {}
     dielectric(double ri, const color& a, shared_ptr<texture> bump, double strength) : ri(ri), albedo(a), bump(bump), strength(strength) {}
     dielectric(double ri, shared_ptr<texture> bump, double strength) : ri(ri), albedo(1.0, 1.0, 1.0), bump(bump), strength(strength) {}
-    bool scatter(const ray&, const hit_record&, color&, ray&) const override { zenith::no_cpu_path("dielectric::scatter"); }
+    bool scatter(const ray& r_in, const hit_record& rec, color& attenuation, ray& scattered) const override { return zenith::device_scatter(*this, r_in, rec, attenuation, scattered); }
     color get_albedo(const hit_record&) const override { return color(1.0, 1.0, 1.0); }
     uint32_t flatten(zenith::scene_builder& b) const override {
         zr_material m{}; m.kind = ZR_MAT_DIELECTRIC; m.tex = ZR_NO_TEXTURE; m.bump_tex = b.texture_id(bump); m.bump_strength = strength; m.param = ri;
@@ -511,7 +525,7 @@ class isovolumetric : public material {
 public:
     isovolumetric(color c) : tex(make_shared<solid_color>(c)) {}
     isovolumetric(shared_ptr<texture> t) : tex(t) {}
-    bool scatter(const ray&, const hit_record&, color&, ray&) const override { zenith::no_cpu_path("isovolumetric::scatter"); }
+    bool scatter(const ray& r_in, const hit_record& rec, color& attenuation, ray& scattered) const override { return zenith::device_scatter(*this, r_in, rec, attenuation, scattered); }
     uint32_t flatten(zenith::scene_builder& b) const override {
         zr_material m{}; m.kind = ZR_MAT_ISOTROPIC; m.tex = b.texture_id(tex); m.bump_tex = ZR_NO_TEXTURE;
         return b.add_material(m);
@@ -534,6 +548,7 @@ inline uint32_t zenith::scene_builder::material_id(const shared_ptr<material>& m
     if (it != mat_ids.end()) return it->second;
     uint32_t id = m->flatten(*this);
     mat_ids[m.get()] = id;
+    mat_ptrs[id] = m;
     return id;
 }
 
@@ -545,7 +560,7 @@ public:
     hittable_list(shared_ptr<hittable> o) { add(o); }
     void clear() { objects.clear(); }
     void add(shared_ptr<hittable> o) { objects.push_back(o); bbox = aabb(bbox, o->bounding_box()); }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("hittable_list::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { for (const auto& o : objects) o->flatten(b); }
 private:
@@ -559,9 +574,9 @@ public:
         vec3 rv(radius, radius, radius);
         bbox = aabb(center - rv, center + rv);  // from the raw argument, like sphere.hpp:13-14
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("sphere::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
-    void set_material(shared_ptr<material> m) { mat = m; }
+    void set_material(shared_ptr<material> m) { mat = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_sphere(center, radius_arg, mat); }
 private:
     point3 center; double radius_arg; shared_ptr<material> mat; aabb bbox;
@@ -571,7 +586,7 @@ class triangle : public hittable {
 public:
     triangle(const point3& a, const point3& b, const point3& c, const vec3& n0, const vec3& n1, const vec3& n2, shared_ptr<material> m)
         : v{a, b, c}, n{n0, n1, n2}, mat(m) {}
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("triangle::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override {  // triangle.hpp:84-101
         double lo[3], hi[3];
         for (int k = 0; k < 3; k++) {
@@ -580,7 +595,7 @@ public:
         }
         return aabb(point3(lo[0], lo[1], lo[2]), point3(hi[0], hi[1], hi[2]));
     }
-    void set_material(shared_ptr<material> m) { mat = m; }
+    void set_material(shared_ptr<material> m) { mat = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_triangle(v, n, mat); }
 private:
     point3 v[3]; vec3 n[3]; shared_ptr<material> mat;
@@ -592,12 +607,12 @@ public:
         half = 0.5 * (mx - mn); center = mn + half;
     }
     cube(const point3& c, shared_ptr<material> mat) : half(1.0, 1.0, 1.0), center(c), mat(mat) { min_p = c - half; max_p = c + half; }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("cube::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override {
         return aabb(interval(min_p.x(), max_p.x()).expand(0.0001), interval(min_p.y(), max_p.y()).expand(0.0001),
                     interval(min_p.z(), max_p.z()).expand(0.0001));
     }
-    void set_material(shared_ptr<material> m) { mat = m; }
+    void set_material(shared_ptr<material> m) { mat = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_cube(half, center, min_p, max_p, mat); }
 private:
     vec3 half; point3 center; shared_ptr<material> mat; point3 min_p, max_p;
@@ -610,7 +625,7 @@ public:
         : boundary(boundary), density(density), phase(make_shared<isovolumetric>(tex)) {}
     constant_medium(shared_ptr<hittable> boundary, double density, color c)
         : boundary(boundary), density(density), phase(make_shared<isovolumetric>(c)) {}
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("constant_medium::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return boundary->bounding_box(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_medium(*boundary, density, b.material_id(phase)); }
 private:
@@ -654,7 +669,7 @@ inline aabb rotated_box(const aabb& in, int axis, double s, double c) {
 class translate : public hittable {
 public:
     translate(shared_ptr<hittable> p, const vec3& displacement) : ptr(p), offset(displacement) { bbox = ptr->bounding_box() + offset; }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("translate::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { b.push_op(ZR_OP_TRANSLATE, offset.x(), offset.y(), offset.z()); ptr->flatten(b); b.pop_op(); }
 private:
@@ -666,7 +681,7 @@ public:
     rotate_y(shared_ptr<hittable> p, double angle_rad) : ptr(p), s(std::sin(angle_rad)), c(std::cos(angle_rad)) {
         bbox = zenith::rotated_box(ptr->bounding_box(), 1, s, c);
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("rotate_y::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { b.push_op(ZR_OP_ROTATE_Y, s, c, 0); ptr->flatten(b); b.pop_op(); }
 private:
@@ -679,7 +694,7 @@ public:
         double r = degrees_to_radians(angle); s = std::sin(r); c = std::cos(r);
         bbox = zenith::rotated_box(ptr->bounding_box(), 0, s, c);
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("rotate_x::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { b.push_op(ZR_OP_ROTATE_X, s, c, 0); ptr->flatten(b); b.pop_op(); }
 private:
@@ -692,7 +707,7 @@ public:
         double r = degrees_to_radians(angle); s = std::sin(r); c = std::cos(r);
         bbox = zenith::rotated_box(ptr->bounding_box(), 2, s, c);
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("rotate_z::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { b.push_op(ZR_OP_ROTATE_Z, s, c, 0); ptr->flatten(b); b.pop_op(); }
 private:
@@ -705,7 +720,7 @@ public:
         aabb in = object->bounding_box();
         bbox = aabb(point3(in.x.min * s.x(), in.y.min * s.y(), in.z.min * s.z()), point3(in.x.max * s.x(), in.y.max * s.y(), in.z.max * s.z()));
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("scale::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void flatten(zenith::scene_builder& b) const override { b.push_op(ZR_OP_SCALE, s.x(), s.y(), s.z()); object->flatten(b); b.pop_op(); }
 private:
@@ -715,9 +730,9 @@ private:
 class material_instance : public hittable {
 public:
     material_instance(shared_ptr<hittable> obj, shared_ptr<material> mat) : object(obj), new_material(mat) {}
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("material_instance::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return object->bounding_box(); }
-    void set_material(shared_ptr<material> m) { new_material = m; }
+    void set_material(shared_ptr<material> m) { new_material = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override {
         // a null material falls back to magenta lambertian (material_instance.hpp:22-26)
         static const shared_ptr<material> error_mat = make_shared<lambertian>(color(1, 0, 1));
@@ -733,7 +748,7 @@ private:
 class bvh_node : public hittable {
 public:
     bvh_node(hittable_list list) : list(std::move(list)) {}
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("bvh_node::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return list.bounding_box(); }
     void flatten(zenith::scene_builder& b) const override { list.flatten(b); }
 private:
@@ -823,7 +838,7 @@ public:
         }
         std::cout << "Model: " << filename << " loaded (" << tris.size() << " triangles)." << std::endl;
     }
-    bool hit(const ray&, interval, hit_record&, int = 0, bool = false) const override { zenith::no_cpu_path("model::hit"); }
+    bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void set_material(std::shared_ptr<material> m) { mat = m; }   // like the reference's: does not re-material existing triangles
     void flatten(zenith::scene_builder& b) const override { for (const auto& t : tris) t->flatten(b); }
@@ -925,12 +940,84 @@ inline zr_env to_zr_env(const EnvironmentSettings& e, scene_builder& b) {
     z.sun_intensity = e.sun_intensity; z.sun_size = e.sun_size;
     return z;
 }
-// one device context per host thread, created on first use
+// one device context per host thread AND device ordinal, created on first use
 inline zr_ctx* thread_context(int device = 0) {
-    struct holder { zr_ctx* c = nullptr; ~holder() { if (c) zr_destroy(c); } };
+    struct holder { std::unordered_map<int, zr_ctx*> c; ~holder() { for (auto& kv : c) if (kv.second) zr_destroy(kv.second); } };
     static thread_local holder h;
-    if (!h.c) h.c = zr_create(device);
-    return h.c;
+    auto it = h.c.find(device);
+    if (it != h.c.end()) return it->second;
+    zr_ctx* c = zr_create(device);
+    if (c) h.c[device] = c;
+    return c;
+}
+
+// ---- callable hit() / scatter(): one ray through the device ---------------------------------------------------------
+// The object is flattened once and committed as a scene of its own (cached in the object, per context; set_material drops
+// the cache, any other mutation of a child after the first call needs zenith::forget(obj)).  hit() = zr_trace over
+// interval [ray_t.min, ray_t.max] with each primitive's own reading of the bounds; scatter() = zr_kat_scatter with the
+// draws taken from the thread's random_double() stream, which is advanced by the number of draws the material made —
+// i.e. the call consumes random_double() exactly as the reference's scatter would (common.hpp:29-34, material.hpp).
+// A constant_medium draws its distance from the off-stream medium key of the current stream position (zr_rng.h).
+struct device_object {
+    zr_ctx* ctx = nullptr; zr_scene* sc = nullptr;
+    flat_scene fs;
+    std::unordered_map<uint32_t, shared_ptr<material>> mats;
+    ~device_object() { if (sc) zr_scene_destroy(sc); }
+};
+template <class Flatten>
+inline shared_ptr<device_object> device_commit(shared_ptr<device_object>& cache, const char* what, Flatten&& flatten) {
+    zr_ctx* ctx = thread_context(0);
+    if (!ctx) throw std::runtime_error(std::string(what) + ": no device context: " + zr_last_error());
+    if (cache && cache->ctx == ctx) return cache;
+    auto d = make_shared<device_object>();
+    d->ctx = ctx;
+    scene_builder b(d->fs);
+    flatten(b);
+    d->mats = b.mat_ptrs;
+    for (const auto& w : d->fs.warnings) std::cerr << "[zenith] " << w << "\n";
+    d->sc = zr_scene_create(ctx);
+    zr_scene_desc desc = d->fs.desc();
+    if (!d->sc || zr_scene_set_all(d->sc, &desc) != ZR_OK || zr_scene_commit(d->sc) != ZR_OK)
+        throw std::runtime_error(std::string(what) + ": " + zr_last_error());
+    cache = d;
+    return d;
+}
+inline void forget(const hittable& h) { h.zr_device_cache_.reset(); }
+inline void forget(const material& m) { m.zr_device_cache_.reset(); }
+
+inline bool device_hit(const hittable& self, const ray& r, const interval& ray_t, hit_record& rec) {
+    auto d = device_commit(self.zr_device_cache_, "hittable::hit", [&](scene_builder& b) { self.flatten(b); });
+    const double rays6[6] = {r.origin().x(), r.origin().y(), r.origin().z(), r.direction().x(), r.direction().y(), r.direction().z()};
+    host_rng& g = rng_state();
+    zr_hit h{};
+    // stream key of this call = (host key, host draw position, 0): a medium's off-stream draw changes as the host stream advances
+    if (zr_trace(d->ctx, d->sc, rays6, 1, ray_t.min, ray_t.max, g.key, g.k, 0, &h) != ZR_OK) throw std::runtime_error(std::string("hittable::hit: ") + zr_last_error());
+    if (!d->fs.media.empty()) g.k++;   // constant_medium::hit consumes a draw (constant_medium.hpp:64)
+    if (h.mat == 0xFFFFFFFFu && h.t == 0.0) return false;
+    rec.p = point3(h.p[0], h.p[1], h.p[2]); rec.normal = vec3(h.normal[0], h.normal[1], h.normal[2]);
+    rec.tangent = vec3(h.tangent[0], h.tangent[1], h.tangent[2]); rec.bitangent = vec3(h.bitangent[0], h.bitangent[1], h.bitangent[2]);
+    rec.t = h.t; rec.u = h.u; rec.v = h.v; rec.front_face = h.front_face != 0;
+    auto it = d->mats.find(h.mat);
+    rec.mat = it != d->mats.end() ? it->second : nullptr;
+    return true;
+}
+
+inline bool device_scatter(const material& self, const ray& r_in, const hit_record& rec, vec3& attenuation, ray& scattered) {
+    uint32_t id = 0;
+    auto d = device_commit(self.zr_device_cache_, "material::scatter", [&](scene_builder& b) { id = self.flatten(b); });
+    id = (uint32_t)d->fs.materials.size() - 1;   // a material flattens its textures first and itself last
+    const double rays6[6] = {r_in.origin().x(), r_in.origin().y(), r_in.origin().z(), r_in.direction().x(), r_in.direction().y(), r_in.direction().z()};
+    zr_hit h{};
+    for (int k = 0; k < 3; k++) { h.p[k] = rec.p[k]; h.normal[k] = rec.normal[k]; h.tangent[k] = rec.tangent[k]; h.bitangent[k] = rec.bitangent[k]; }
+    h.t = rec.t; h.u = rec.u; h.v = rec.v; h.mat = id; h.front_face = rec.front_face ? 1u : 0u;
+    host_rng& g = rng_state();
+    zr_scatter_out o{};
+    if (zr_kat_scatter(d->ctx, d->sc, rays6, &h, &g.key, &g.k, 1, &o) != ZR_OK) throw std::runtime_error(std::string("material::scatter: ") + zr_last_error());
+    g.k += o.draws;
+    if (!o.scattered) return false;
+    attenuation = vec3(o.attenuation[0], o.attenuation[1], o.attenuation[2]);
+    scattered = ray(point3(o.origin[0], o.origin[1], o.origin[2]), vec3(o.direction[0], o.direction[1], o.direction[2]));
+    return true;
 }
 }  // namespace zenith
 

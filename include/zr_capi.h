@@ -232,6 +232,10 @@ int zr_scene_commit(zr_scene*);
 /* sizes of the committed scene: out[0]=bvh nodes (child-pair records), [1]=max depth, [2]=objects,
  * [3]=device bytes */
 int zr_scene_stats(const zr_scene*, uint64_t out[4]);
+/* traversal-stack bound of the committed scene: the exact worst-case number of entries one ray's stack can hold while
+ * walking the 4-wide tree (the recursion depth of bvh_node::hit, bvh.hpp:46-54, has no bound in the reference; here the
+ * per-wave spill slabs are sized from this number, so no scene can overrun them); 0 = not committed */
+uint32_t zr_scene_traversal_stack(const zr_scene*);
 
 /* ---- render: replaces camera::render's sample loop (camera.hpp:236-248, 404-579) ----------- */
 /* Fills out_rgb[(j*W+i)*3 + c] (host memory, W*H*3 doubles, row 0 = top, mean over spp — the layout of
@@ -329,6 +333,29 @@ void zr_comm_destroy(zr_comm*);
  * zr_stream_key(seed, pixel, k) and `bounce`. */
 int zr_trace(zr_ctx*, const zr_scene*, const double* rays6, size_t n, double tmin, double tmax,
              uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* out);
+
+/* ---- per-function known-answer entry points -------------------------------------------------------------------------
+ * The reference's seam is its virtual API (hittable::hit hittable.hpp:29-36, material::scatter / emitted material.hpp:7-31,
+ * texture::value texture.hpp:6-10) plus camera::get_ray / get_background_color (camera.hpp:784-794, 828-925).  zr_trace above
+ * answers hittable::hit; the four calls below answer the others, n calls per launch, with the device arithmetic of the
+ * render kernels.  They serve the parity tests (hand-placed edge cases against the genuine reference) and the drop-in
+ * classes' hit() / scatter() / emitted() in include/zenith/zenith.hpp, which stay callable without any CPU evaluation. */
+typedef struct zr_scatter_out {
+    double attenuation[3], origin[3], direction[3];  /* material::scatter's outputs (zero when it returned false) */
+    double emitted[3];                                /* material::emitted(rec.u, rec.v, rec.p) */
+    uint32_t scattered;                               /* scatter's return value */
+    uint32_t draws;                                   /* random_double() calls it made */
+} zr_scatter_out;
+/* material::scatter(r_in, rec, attenuation, scattered) and emitted for n (ray, hit record) pairs; recs[k].mat indexes the
+ * scene's materials; draws come from the contract stream keys[k] (include/zr_rng.h), starting at draw first_draw[k] (NULL = 0) */
+int zr_kat_scatter(zr_ctx*, const zr_scene*, const double* rays6, const zr_hit* recs, const uint64_t* keys, const uint64_t* first_draw,
+                   size_t n, zr_scatter_out* out);
+/* texture::value(u, v, p) of the scene's texture `texture_id`; uvp5 = n x (u, v, px, py, pz); out = n x rgb */
+int zr_kat_texture(zr_ctx*, const zr_scene*, uint32_t texture_id, const double* uvp5, size_t n, double* out_rgb);
+/* camera::get_background_color(ray(., dir), env) for n directions (env.hdr_texture indexes the scene's textures) */
+int zr_kat_background(zr_ctx*, const zr_scene*, const zr_env*, const double* dirs3, size_t n, double* out_rgb);
+/* camera::get_ray(i, j) after camera::initialize() for n requests (i, j, sample); out = n x (origin, direction, draws used) */
+int zr_kat_camera_rays(zr_ctx*, const zr_camera*, uint64_t seed, const int32_t* requests3, size_t n, double* out7);
 
 #ifdef __cplusplus
 }

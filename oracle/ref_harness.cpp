@@ -287,6 +287,7 @@ static int usage() {
                  "  zenith_ref aov    <scene> <x0> <y0> <w> <h> <zmax> <out_prefix> - [a0 a1 a2 a3]\n"
                  "  zenith_ref passes <scene> <x0> <y0> <w> <h> <spp|0> <out_prefix> [a0 a1 a2 a3]\n"
                  "  zenith_ref post   <scene> <preset 0-7> <out_prefix> [spp]\n"
+                 "  zenith_ref kat    <scene> hits|tex|bg|cam <in.bin> <n> <out_prefix>\n"
                  "  zenith_ref texels <w> <h> <out.npy>\n");
     return 2;
 }
@@ -577,6 +578,113 @@ int main(int argc, char** argv) {
         write_npy(out + "_recs.npy", "<f8", {n, 16}, recs.data(), recs.size() * 8);
         std::printf("{\"scene\": \"%s\", \"rays\": %zu, \"seed\": %llu, \"stream_pixel\": %llu}\n", argv[2], n,
                     (unsigned long long)seed, 0x7ACEull);
+        cleanup(b);
+        return 0;
+    }
+
+    if (cmd == "kat" && argc >= 7) {
+        // zenith_ref kat <scene> hits|tex|bg|cam <in.bin> <n> <out_prefix>: per-function known answers on HAND-PLACED inputs
+        // (raw little-endian doubles in, .npy out); the callee is always the genuine reference function:
+        //   hits  n x (o, d, tmin, tmax)        -> world.hit(r, interval(tmin, tmax), rec) through bvh_node, then rec.mat->emitted and
+        //                                          rec.mat->scatter with the stream (seed, 0x7ACE, k) at draw 0
+        //   tex   n x (index, u, v, p)          -> zr_demo_scene::kat_textures[index]->value(u, v, p)
+        //   bg    n x (mode, bg rgb, intensity, yaw, tilt, roll, sun dir, sun colour, sun intensity, sun size, dir)
+        //                                       -> camera::get_background_color (HDR_MAP uses the scene's own hdr_texture)
+        //   cam   n x (i, j, sample)            -> camera::initialize + get_ray(i, j) on the stream (scene seed, j W + i, sample)
+        built_scene b;
+        if (!build(b, argv[2], 0, 0, 0, 0)) return usage();
+        const std::string what = argv[3];
+        const size_t n = (size_t)std::atoll(argv[5]);
+        const std::string out = argv[6];
+        const size_t width = what == "hits" ? 8 : what == "tex" ? 6 : what == "bg" ? 19 : what == "cam" ? 3 : 0;
+        if (!width) return usage();
+        std::vector<double> in(n * width);
+        { FILE* f = std::fopen(argv[4], "rb"); if (!f || std::fread(in.data(), 8, in.size(), f) != in.size()) { std::fprintf(stderr, "cannot read %s\n", argv[4]); return 2; } std::fclose(f); }
+        if (what == "hits") {
+            std::vector<double> recs(n * 16, 0.0), scat(n * 14, 0.0);
+            std::map<const material*, int> mat_id;
+            probe_world world(*b.bvh);
+            const uint64_t seed = 0x5EED3001ull;
+            for (size_t k = 0; k < n; k++) {
+                const double* q = &in[k * 8];
+                ray r(point3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]));
+                zr_oracle_seed(seed, 0x7ACEull, k);
+                hit_record rec;
+                probe_world::sample_segments() = 0;
+                bool h = world.hit(r, interval(q[6], q[7]), rec);
+                double* e = &recs[k * 16];
+                if (!h) continue;
+                int id;
+                auto it = mat_id.find(rec.mat.get());
+                if (it == mat_id.end()) { id = (int)mat_id.size(); mat_id[rec.mat.get()] = id; } else id = it->second;
+                e[0] = 1; e[1] = rec.t; e[2] = rec.p.x(); e[3] = rec.p.y(); e[4] = rec.p.z();
+                e[5] = rec.normal.x(); e[6] = rec.normal.y(); e[7] = rec.normal.z();
+                e[8] = rec.front_face ? 1 : 0; e[9] = rec.u; e[10] = rec.v;
+                e[11] = rec.tangent.x(); e[12] = rec.tangent.y(); e[13] = rec.tangent.z();
+                e[14] = id;
+                double* sc = &scat[k * 14];
+                color em = rec.mat->emitted(rec.u, rec.v, rec.p);
+                ray scattered; color att;
+                zr_oracle_tls.k = 0;
+                const uint64_t d0 = zr_oracle_tls.draws;
+                bool ok = rec.mat->scatter(r, rec, att, scattered);
+                sc[0] = ok ? 1 : 0;
+                if (ok) {
+                    sc[1] = att.x(); sc[2] = att.y(); sc[3] = att.z();
+                    sc[4] = scattered.origin().x(); sc[5] = scattered.origin().y(); sc[6] = scattered.origin().z();
+                    sc[7] = scattered.direction().x(); sc[8] = scattered.direction().y(); sc[9] = scattered.direction().z();
+                }
+                sc[10] = em.x(); sc[11] = em.y(); sc[12] = em.z();
+                sc[13] = (double)(zr_oracle_tls.draws - d0);
+            }
+            write_npy(out + "_recs.npy", "<f8", {n, 16}, recs.data(), recs.size() * 8);
+            write_npy(out + "_scat.npy", "<f8", {n, 14}, scat.data(), scat.size() * 8);
+            std::printf("{\"scene\": \"%s\", \"what\": \"hits\", \"n\": %zu, \"seed\": %llu, \"stream_pixel\": %llu}\n", argv[2], n, (unsigned long long)seed, 0x7ACEull);
+        } else if (what == "tex") {
+            std::vector<double> rgb(n * 3);
+            for (size_t k = 0; k < n; k++) {
+                const double* q = &in[k * 6];
+                const size_t idx = (size_t)q[0];
+                if (idx >= b.s.kat_textures.size()) { std::fprintf(stderr, "texture index out of range\n"); return 2; }
+                color c = b.s.kat_textures[idx]->value(q[1], q[2], point3(q[3], q[4], q[5]));
+                rgb[k * 3] = c.x(); rgb[k * 3 + 1] = c.y(); rgb[k * 3 + 2] = c.z();
+            }
+            write_npy(out + "_rgb.npy", "<f8", {n, 3}, rgb.data(), rgb.size() * 8);
+            std::printf("{\"scene\": \"%s\", \"what\": \"tex\", \"n\": %zu, \"textures\": %zu}\n", argv[2], n, b.s.kat_textures.size());
+        } else if (what == "bg") {
+            std::vector<double> rgb(n * 3);
+            ref_camera cam; cam.c = b.s.cam; cam.setup();
+            for (size_t k = 0; k < n; k++) {
+                const double* q = &in[k * 19];
+                EnvironmentSettings env;
+                env._mode = (EnvironmentSettings::Mode)(int)q[0];
+                env.background_color = color(q[1], q[2], q[3]); env.intensity = q[4];
+                env.hdri_rotation = q[5]; env.hdri_tilt = q[6]; env.hdri_roll = q[7];
+                env.sun_direction = vec3(q[8], q[9], q[10]); env.sun_color = color(q[11], q[12], q[13]);
+                env.sun_intensity = q[14]; env.sun_size = q[15];
+                if (env._mode == EnvironmentSettings::HDR_MAP) env.hdr_texture = b.s.env.hdr_texture;
+                color c = cam.get_background_color(ray(point3(0, 0, 0), vec3(q[16], q[17], q[18])), env);
+                rgb[k * 3] = c.x(); rgb[k * 3 + 1] = c.y(); rgb[k * 3 + 2] = c.z();
+            }
+            write_npy(out + "_rgb.npy", "<f8", {n, 3}, rgb.data(), rgb.size() * 8);
+            std::printf("{\"scene\": \"%s\", \"what\": \"bg\", \"n\": %zu}\n", argv[2], n);
+        } else {
+            std::vector<double> rays(n * 7);
+            ref_camera cam; cam.c = b.s.cam; cam.setup();
+            for (size_t k = 0; k < n; k++) {
+                const int i = (int)in[k * 3], j = (int)in[k * 3 + 1], smp = (int)in[k * 3 + 2];
+                zr_oracle_seed(b.s.seed, (uint64_t)j * cam.image_width + i, (uint64_t)smp);
+                const uint64_t d0 = zr_oracle_tls.draws;
+                ray r = cam.get_ray(i, j);
+                double* o = &rays[k * 7];
+                o[0] = r.origin().x(); o[1] = r.origin().y(); o[2] = r.origin().z();
+                o[3] = r.direction().x(); o[4] = r.direction().y(); o[5] = r.direction().z();
+                o[6] = (double)(zr_oracle_tls.draws - d0);
+            }
+            write_npy(out + "_rays.npy", "<f8", {n, 7}, rays.data(), rays.size() * 8);
+            std::printf("{\"scene\": \"%s\", \"what\": \"cam\", \"n\": %zu, \"seed\": %llu, \"image_width\": %d, \"image_height\": %d}\n", argv[2], n,
+                        (unsigned long long)b.s.seed, cam.image_width, cam.image_height);
+        }
         cleanup(b);
         return 0;
     }

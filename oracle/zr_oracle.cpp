@@ -1006,4 +1006,61 @@ int zro_scatter(void* scene, const double* ray6, const zr_hit* h, uint64_t key, 
     return s ? 1 : 0;
 }
 
+// ---- per-function known answers, the CPU side of the zr_kat_* entry points of include/zr_capi.h ------------------------
+// material::scatter + emitted with the stream `key` positioned at draw `first_draw`
+int zro_kat_scatter(void* scene, const double* rays6, const zr_hit* recs, const uint64_t* keys, const uint64_t* first_draw, size_t n,
+                    zr_scatter_out* out) {
+    const Scene& sc = *(Scene*)scene;
+    for (size_t q = 0; q < n; q++) {
+        const double* ray6 = rays6 + q * 6; const zr_hit* h = recs + q;
+        Ray r{V3(ray6[0], ray6[1], ray6[2]), V3(ray6[3], ray6[4], ray6[5])};
+        Rec rec;
+        for (int k = 0; k < 3; k++) { rec.p[k] = h->p[k]; rec.n[k] = h->normal[k]; rec.tan[k] = h->tangent[k]; rec.bit[k] = h->bitangent[k]; }
+        rec.t = h->t; rec.u = h->u; rec.v = h->v; rec.mat = h->mat; rec.front = h->front_face != 0;
+        Rng g; g.key = keys[q]; g.k = first_draw ? first_draw[q] : 0;
+        V3 att(0, 0, 0); Ray nr{V3(0, 0, 0), V3(0, 0, 0)};
+        V3 em = sc.emitted(rec);
+        bool ok = sc.scatter(r, rec, att, nr, g);
+        zr_scatter_out& o = out[q];
+        std::memset(&o, 0, sizeof o);
+        for (int k = 0; k < 3; k++) { o.emitted[k] = em[k]; if (ok) { o.attenuation[k] = att[k]; o.origin[k] = nr.o[k]; o.direction[k] = nr.d[k]; } }
+        o.scattered = ok ? 1u : 0u; o.draws = (uint32_t)g.draws;
+    }
+    return ZR_OK;
+}
+
+int zro_kat_texture(void* scene, uint32_t tex, const double* uvp5, size_t n, double* out_rgb) {
+    const Scene& sc = *(Scene*)scene;
+    if (tex >= sc.d.n_textures) return ZR_E_INVALID;
+    for (size_t q = 0; q < n; q++) {
+        const double* a = uvp5 + q * 5;
+        V3 c = sc.tex_value(tex, a[0], a[1], V3(a[2], a[3], a[4]));
+        for (int k = 0; k < 3; k++) out_rgb[q * 3 + k] = c[k];
+    }
+    return ZR_OK;
+}
+
+int zro_kat_background(void* scene, const zr_env* env, const double* dirs3, size_t n, double* out_rgb) {
+    const Scene& sc = *(Scene*)scene;
+    for (size_t q = 0; q < n; q++) {
+        Ray r{V3(0, 0, 0), V3(dirs3[q * 3], dirs3[q * 3 + 1], dirs3[q * 3 + 2])};
+        V3 c = background(sc, *env, r);
+        for (int k = 0; k < 3; k++) out_rgb[q * 3 + k] = c[k];
+    }
+    return ZR_OK;
+}
+
+int zro_kat_camera_rays(const zr_camera* cam_in, uint64_t seed, const int32_t* req3, size_t n, double* out7) {
+    Cam cam; cam.c = *cam_in; cam.initialize();
+    const int W = cam.c.image_width;
+    for (size_t q = 0; q < n; q++) {
+        const int i = req3[q * 3], j = req3[q * 3 + 1], smp = req3[q * 3 + 2];
+        Rng g; g.key = zr_stream_key(seed, (uint64_t)j * W + i, (uint64_t)smp);
+        Ray r = cam.get_ray(i, j, g);
+        for (int k = 0; k < 3; k++) { out7[q * 7 + k] = r.o[k]; out7[q * 7 + 3 + k] = r.d[k]; }
+        out7[q * 7 + 6] = (double)g.draws;
+    }
+    return ZR_OK;
+}
+
 }  // extern "C"

@@ -47,6 +47,10 @@ def load():
     lib.zro_auto_exposure.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.zro_trace.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_uint32, vp]
     lib.zro_scatter.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    lib.zro_kat_scatter.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.zro_kat_texture.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp]
+    lib.zro_kat_background.argtypes = [vp, C.POINTER(capi.Env), vp, C.c_size_t, vp]
+    lib.zro_kat_camera_rays.argtypes = [C.POINTER(capi.Camera), C.c_uint64, vp, C.c_size_t, vp]
     _lib = lib
     return lib
 
@@ -110,6 +114,30 @@ class OracleScene:
         ok = self.lib.zro_scatter(self._s, ray.ctypes.data, h.ctypes.data, C.c_uint64(key), att.ctypes.data, out.ctypes.data)
         return bool(ok), att, out
 
+    # ---- per-function known answers (the CPU side of capi.Scene.kat_*) ----
+    def kat_scatter(self, rays, hits, keys, first_draw=None):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        hits = np.ascontiguousarray(hits, dtype=capi.HIT_DTYPE)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        fd = np.ascontiguousarray(first_draw, dtype=np.uint64) if first_draw is not None else None
+        out = np.zeros(len(rays), dtype=capi.SCATTER_DTYPE)
+        rc = self.lib.zro_kat_scatter(self._s, rays.ctypes.data, hits.ctypes.data, keys.ctypes.data, fd.ctypes.data if fd is not None else None,
+                                      len(rays), out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def kat_texture(self, tex, uvp):
+        uvp = np.ascontiguousarray(uvp, dtype=np.float64).reshape(-1, 5)
+        out = np.zeros((len(uvp), 3))
+        assert self.lib.zro_kat_texture(self._s, int(tex), uvp.ctypes.data, len(uvp), out.ctypes.data) == 0
+        return out
+
+    def kat_background(self, env, dirs):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((len(dirs), 3))
+        assert self.lib.zro_kat_background(self._s, C.byref(env), dirs.ctypes.data, len(dirs), out.ctypes.data) == 0
+        return out
+
     def close(self):
         if self._s:
             self.lib.zro_scene_destroy(self._s)
@@ -120,6 +148,14 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def kat_camera_rays(camera, seed, requests):
+    """camera::initialize + get_ray of the CPU restatement: (n, 7) = origin, direction, draws"""
+    req = np.ascontiguousarray(requests, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((len(req), 7))
+    assert load().zro_kat_camera_rays(C.byref(camera), C.c_uint64(seed), req.ctypes.data, len(req), out.ctypes.data) == 0
+    return out
 
 
 def post_process(params, frame, is_data_pass=False, apply_gamma=True):

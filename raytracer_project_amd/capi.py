@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libzr_hip.so")
+# ZR_LIB: development override (scripts/ab_flags.sh, scripts/wave_profile.sh build experimental variants out of tree)
+LIB_PATH = os.environ.get("ZR_LIB") or os.path.join(_HERE, "csrc", "libzr_hip.so")
 SCENES_LIB_PATH = os.path.join(_HERE, "csrc", "libzr_scenes.so")
 
 ZR_OK, ZR_E_INVALID, ZR_E_DEVICE, ZR_E_STATE, ZR_E_CANCELLED = 0, -1, -2, -3, -4
@@ -125,6 +126,16 @@ HIT_DTYPE = np.dtype([("p", "<f8", 3), ("normal", "<f8", 3), ("tangent", "<f8", 
 assert HIT_DTYPE.itemsize == C.sizeof(Hit)
 
 
+class ScatterOut(C.Structure):
+    _fields_ = [("attenuation", C.c_double * 3), ("origin", C.c_double * 3), ("direction", C.c_double * 3), ("emitted", C.c_double * 3),
+                ("scattered", C.c_uint32), ("draws", C.c_uint32)]
+
+
+SCATTER_DTYPE = np.dtype([("attenuation", "<f8", 3), ("origin", "<f8", 3), ("direction", "<f8", 3), ("emitted", "<f8", 3),
+                          ("scattered", "<u4"), ("draws", "<u4")])
+assert SCATTER_DTYPE.itemsize == C.sizeof(ScatterOut)
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("spheres", C.c_void_p), ("sphere_mat", C.c_void_p), ("n_spheres", C.c_uint64),
                 ("tri_v", C.c_void_p), ("tri_n", C.c_void_p), ("tri_mat", C.c_void_p), ("n_tris", C.c_uint64),
@@ -145,8 +156,8 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
-    "zr_get_kernel_times", "zr_trace", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
+    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
+    "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
 ]
 
 
@@ -177,6 +188,7 @@ def load():
     lib.zr_scene_set_textures.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     lib.zr_scene_commit.argtypes = [vp]
     lib.zr_scene_stats.argtypes = [vp, C.POINTER(u64 * 4)]
+    lib.zr_scene_traversal_stack.argtypes = [vp]; lib.zr_scene_traversal_stack.restype = C.c_uint32
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
     lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
@@ -187,6 +199,10 @@ def load():
     lib.zr_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.zr_get_kernel_times.argtypes = [vp, C.POINTER(C.c_float), i32]
     lib.zr_trace.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, u64, u64, C.c_uint32, vp]
+    lib.zr_kat_scatter.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.zr_kat_texture.argtypes = [vp, vp, C.c_uint32, vp, C.c_size_t, vp]
+    lib.zr_kat_background.argtypes = [vp, vp, C.POINTER(Env), vp, C.c_size_t, vp]
+    lib.zr_kat_camera_rays.argtypes = [vp, C.POINTER(Camera), u64, vp, C.c_size_t, vp]
     lib.zr_comm_unique_id.argtypes = [vp]
     lib.zr_comm_create.restype = vp; lib.zr_comm_create.argtypes = [vp, i32, i32, vp]
     lib.zr_comm_reduce_frame.argtypes = [vp, vp, C.c_size_t, i32, vp]
@@ -241,6 +257,9 @@ class DemoScene:
         self.env = s.zrs_env(self._h).contents
         self.seed = int(s.zrs_seed(self._h))
         self.warnings = s.zrs_warnings(self._h).decode()
+        ids = (C.c_uint32 * 64)()
+        s.zrs_kat_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.kat_textures = [int(ids[k]) for k in range(min(64, s.zrs_kat_textures(self._h, ids, 64)))]
 
     def render_dropin(self, width=0, height=0, spp=0, device=0):
         """camera::render(world, env, post, flag) of include/zenith/zenith.hpp, end to end."""
@@ -252,6 +271,17 @@ class DemoScene:
         if rc != 0:
             raise ZrError(f"drop-in render failed: {load().zr_last_error().decode()}")
         return out, ctr
+
+    def dropin_virtuals(self, rays8, seed, pixel=0x7ACE):
+        """bvh_node(world).hit + rec.mat->emitted / scatter through the drop-in classes (one device launch per call):
+        (recs[n,16], scat[n,14]) in the layout of `zenith_ref kat <scene> hits`"""
+        rays8 = np.ascontiguousarray(rays8, dtype=np.float64).reshape(-1, 8)
+        recs = np.zeros((len(rays8), 16)); scat = np.zeros((len(rays8), 14))
+        lib = load_scenes()
+        lib.zrs_dropin_virtuals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        if lib.zrs_dropin_virtuals(self._h, rays8.ctypes.data, len(rays8), seed, pixel, recs.ctypes.data, scat.ctypes.data) != 0:
+            raise ZrError("drop-in hit()/scatter() failed (see stderr)")
+        return recs, scat
 
     def dropin_frame_to_rgb8(self, spp=0, device=0):
         """render (auto-exposure, reflection split) + post stack through include/zenith/zenith.hpp: (rgb8, reflection8, exposure)"""
@@ -310,6 +340,13 @@ class Context:
         _check(self.lib.zr_analyze_frame(self._c, frame.ctypes.data, frame.size // 3, C.byref(st)))
         return st
 
+    def kat_camera_rays(self, camera, seed, requests):
+        """camera::initialize + get_ray: (n, 7) = origin, direction, draws"""
+        req = np.ascontiguousarray(requests, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros((len(req), 7))
+        _check(self.lib.zr_kat_camera_rays(self._c, C.byref(camera), C.c_uint64(seed), req.ctypes.data, len(req), out.ctypes.data))
+        return out
+
     def counters(self):
         c = Counters()
         _check(self.lib.zr_get_counters(self._c, C.byref(c)))
@@ -336,7 +373,8 @@ class Scene:
     def stats(self):
         out = (C.c_uint64 * 4)()
         _check(self.lib.zr_scene_stats(self._s, C.byref(out)))
-        return {"bvh_pairs": out[0], "bvh_depth": out[1], "objects": out[2], "device_bytes": out[3]}
+        return {"bvh_pairs": out[0], "bvh_depth": out[1], "objects": out[2], "device_bytes": out[3],
+                "traversal_stack": int(self.lib.zr_scene_traversal_stack(self._s))}
 
     def render(self, camera, env, seed, region=None, count=False, out=None):
         h, w = camera.image_height, camera.image_width
@@ -388,6 +426,30 @@ class Scene:
         out = np.zeros(n, dtype=HIT_DTYPE)
         _check(self.lib.zr_trace(self.ctx._c, self._s, rays.ctypes.data, n, tmin, tmax, C.c_uint64(seed),
                                  C.c_uint64(pixel), bounce, out.ctypes.data))
+        return out
+
+    # ---- per-function known-answer entry points (zr_kat_*) ----
+    def kat_scatter(self, rays, hits, keys, first_draw=None):
+        """material::scatter + emitted for (ray, hit record) pairs -> array of SCATTER_DTYPE"""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        fd = np.ascontiguousarray(first_draw, dtype=np.uint64) if first_draw is not None else None
+        out = np.zeros(len(rays), dtype=SCATTER_DTYPE)
+        _check(self.lib.zr_kat_scatter(self.ctx._c, self._s, rays.ctypes.data, hits.ctypes.data, keys.ctypes.data,
+                                       fd.ctypes.data if fd is not None else None, len(rays), out.ctypes.data))
+        return out
+
+    def kat_texture(self, tex, uvp):
+        uvp = np.ascontiguousarray(uvp, dtype=np.float64).reshape(-1, 5)
+        out = np.zeros((len(uvp), 3))
+        _check(self.lib.zr_kat_texture(self.ctx._c, self._s, int(tex), uvp.ctypes.data, len(uvp), out.ctypes.data))
+        return out
+
+    def kat_background(self, env, dirs):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((len(dirs), 3))
+        _check(self.lib.zr_kat_background(self.ctx._c, self._s, C.byref(env), dirs.ctypes.data, len(dirs), out.ctypes.data))
         return out
 
     def close(self):

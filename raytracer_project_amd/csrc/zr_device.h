@@ -367,13 +367,14 @@ __device__ __forceinline__ void slab_constants(double d, double o, double& id, d
 
 // ---- closest hit: BVH walk (replaces bvh_node::hit, bvh.hpp:46-54,112-118 + aabb::hit, aabb.hpp:44-66) ----
 // `stack` is this lane's column of the workgroup's LDS traversal stack: entry i lives at stack[i * stride].
-// Returns the leaf object and distance of the closest hit in (tmin, +inf).
+// Returns the leaf object and distance of the closest hit in the interval (tmin, tmax) — each primitive applies its own
+// reading of the bounds, as in the reference (sphere: open, triangle: closed, cube: clamps to them).
 template <bool COUNT>
 __device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, const Rng& g, uint32_t* stack, int stride,
-                                   double& t_out, uint32_t& kind_out, uint32_t& idx_out, Counters& ctr) {
+                                   double& t_out, uint32_t& kind_out, uint32_t& idx_out, Counters& ctr, double tmax = __builtin_huge_val()) {
     double idx_, idy_, idz_, ox_, oy_, oz_;
     slab_constants(r.d.x, r.o.x, idx_, ox_); slab_constants(r.d.y, r.o.y, idy_, oy_); slab_constants(r.d.z, r.o.z, idz_, oz_);
-    double tbest = __builtin_huge_val();
+    double tbest = tmax;
     uint32_t kbest = 0xFFFFFFFFu, ibest = 0;
     int sp = 0;
     uint32_t cur = 0;  // NodePair index

@@ -96,6 +96,7 @@ struct zr_ctx {
     DevBuf<unsigned long long> d_cpart;    // ... and the per-block counters of the two passes
     DevBuf<unsigned int> d_ctl;
     DevBuf<unsigned char> d_st_overflow;
+    uint32_t st_ovf_levels = 0;           // levels per lane the spill slabs of d_st_overflow hold
     int st_blocks = 0;
     uint32_t st_slots = 0;
     int st_pools = -1;                    // sub-pools staggered on separate streams: 1 = one pool, -1 = auto
@@ -143,6 +144,7 @@ struct zr_scene {
     DevBuf<unsigned char> d_texels;
     zr::DScene ds{};
     bool generic_leaves = true;   // the BVH has leaves other than bare triangles / spheres
+    uint32_t stack_demand = 0;    // worst-case entries on an EXTEND lane's traversal stack (Flattener::stack_demand)
     uint64_t stats[4] = {0, 0, 0, 0};
 };
 
@@ -547,6 +549,20 @@ struct Flattener {
         quads[q] = nq;
         return q;
     }
+    // Worst-case number of entries the EXTEND kernel's per-lane stack holds for this 4-wide tree: visiting a node whose
+    // nk children are all hit pushes nk - 1 of them and descends into the nearest (any child can be the nearest), or
+    // pushes all nk when the nearest is a leaf and the lane already holds a postponed leaf (zr_stream.hip).
+    // demand(node) = max(nk, max over inner children c of nk - 1 + demand(c)); exact, by DFS over the emitted nodes.
+    uint32_t demand_of(const uint32_t refs[4]) const {
+        uint32_t nk = 0, best = 0;
+        for (int k = 0; k < 4; k++) if (refs[k] != ZR_REF_EMPTY) nk++;
+        for (int k = 0; k < 4; k++) {
+            if (refs[k] == ZR_REF_EMPTY || (refs[k] & ZR_REF_LEAF)) continue;
+            best = std::max(best, demand_of(quads[refs[k]].ref));
+        }
+        return std::max(nk, nk ? nk - 1 + best : 0u);
+    }
+    uint32_t stack_demand() const { return demand_of(root.ref); }
     void run() {
         leaf_first.assign(br.nodes.size(), 0);
         if (br.nodes.empty()) {
@@ -604,10 +620,12 @@ zr_ctx* zr_create(int device_ordinal) {
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
         if (over > 0) c->st_blocks = over;
         c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
-        c->st_slots = std::max<uint32_t>(4096, c->st_slots / 64 * 64);
+        // dynamic work units of shard s are handed out only by SHADE blocks with blockIdx % 64 == s (zr_stream.hip): a pool needs at
+        // least 64 SHADE blocks (64 x 256 slots) or the units of the unserved shards would never be rendered
+        c->st_slots = std::max<uint32_t>(64u * 256u, c->st_slots / 256 * 256);
         c->st_pools = (int)env_double("ZR_STREAM_POOLS", -1);
         if (env_double("ZR_STREAM_OVERLAP", -1) == 0) c->st_pools = 1;
-        if (c->d_ctl.alloc((ST_MAX_POOLS + 1) * zr::stream_ctl_words()) != ZR_OK || c->d_st_overflow.alloc(ST_MAX_POOLS * zr::stream_overflow_bytes(c->st_blocks)) != ZR_OK ||
+        if (c->d_ctl.alloc((ST_MAX_POOLS + 1) * zr::stream_ctl_words()) != ZR_OK ||
             hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&c->h_active, ST_MAX_POOLS * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
@@ -826,6 +844,8 @@ int zr_scene_commit(zr_scene* s) {
     d.n_mats = (uint32_t)s->materials.size();
     d.root = fl.root;
     s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
+    s->stack_demand = fl.stack_demand();
+    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", fl.quad_depth, s->stack_demand);
     s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
     s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
@@ -838,6 +858,8 @@ int zr_scene_stats(const zr_scene* s, uint64_t out[4]) {
     std::memcpy(out, s->stats, sizeof s->stats);
     return ZR_OK;
 }
+
+uint32_t zr_scene_traversal_stack(const zr_scene* s) { return s && s->committed ? s->stack_demand : 0u; }
 
 }  // extern "C"
 
@@ -930,6 +952,19 @@ int make_plan(const zr_camera& cam, const zr_region* region, Plan& p) {
 
 int resolve_times(zr_ctx* c);
 
+// spill slabs of the EXTEND traversal stack, sized for the deepest tree this context has met (never below 36 levels, the
+// fixed size of round 1): one slab per resident wave and sub-pool
+int ensure_stack_slabs(zr_ctx* c, const zr_scene* s) {
+    const uint32_t need = std::max<uint32_t>(36u, zr::stream_overflow_levels(s->stack_demand));
+    if (need <= c->st_ovf_levels && c->d_st_overflow.p) return ZR_OK;
+    HIP_OK(hipDeviceSynchronize());
+    c->d_st_overflow.release();
+    int rc = c->d_st_overflow.alloc(ST_MAX_POOLS * zr::stream_overflow_bytes(c->st_blocks, need));
+    if (rc) { c->st_ovf_levels = 0; return rc; }
+    c->st_ovf_levels = need;
+    return ZR_OK;
+}
+
 struct HostTimer : zr::StreamTimer {
     zr_ctx* c; hipEvent_t cur_a = nullptr; bool ok = true;
     explicit HostTimer(zr_ctx* c) : c(c) {}
@@ -989,6 +1024,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
         if (units < P) P = (uint32_t)((units + 63) / 64 * 64);
     }
     int rc;
+    if ((rc = ensure_stack_slabs(c, s))) return rc;
     if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS))) return rc;
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
@@ -1008,7 +1044,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const bool sharded = (size_t)plan.tiles.size() < (size_t)plan.tiles_x * plan.tiles_y;
     const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
-                                     c->d_st_overflow.p, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
+                                     c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
                                      keep_going, &rounds, s->generic_leaves, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
@@ -1382,9 +1418,10 @@ int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double
         return fail(ZR_E_INVALID, "ZR_TRACE_ENGINE=extend needs ZR_KERNEL=2, tmin = 0.001, tmax = inf and a scene within the 4-wide tree's limits");
     if (can_extend && !(eng && std::strcmp(eng, "pairs") == 0)) {
         DevBuf<unsigned char> pool;
+        if ((rc = ensure_stack_slabs(c, s))) return rc;
         if ((rc = pool.alloc(zr::stream_pool_bytes((uint32_t)n) + 65536))) return rc;
         HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
-        HIP_OK(zr::stream_trace(s->ds, d_rays.p, (uint32_t)n, seed, pixel, bounce, d_hits.p, pool.p, c->d_ctl.p, c->d_st_overflow.p, c->st_blocks,
+        HIP_OK(zr::stream_trace(s->ds, d_rays.p, (uint32_t)n, seed, pixel, bounce, d_hits.p, pool.p, c->d_ctl.p, c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks,
                                 c->d_ctr.p, s->generic_leaves, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
         unsigned int capped = 0;
@@ -1395,6 +1432,75 @@ int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double
         HIP_OK(hipStreamSynchronize(c->stream));
     }
     if (n) HIP_OK(hipMemcpy(out, d_hits.p, n * sizeof(zr_hit), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+int zr_kat_scatter(zr_ctx* c, const zr_scene* s, const double* rays6, const zr_hit* recs, const uint64_t* keys, const uint64_t* first_draw,
+                   size_t n, zr_scatter_out* out) {
+    if (!c || !s || (n && (!rays6 || !recs || !keys || !out))) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_kat_scatter");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    if (n == 0) return ZR_OK;
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<double> d_rays; DevBuf<zr_hit> d_recs; DevBuf<uint64_t> d_keys, d_first; DevBuf<zr_scatter_out> d_out;
+    int rc;
+    if ((rc = d_rays.upload(std::vector<double>(rays6, rays6 + n * 6))) || (rc = d_recs.upload(std::vector<zr_hit>(recs, recs + n))) ||
+        (rc = d_keys.upload(std::vector<uint64_t>(keys, keys + n))) || (rc = d_out.alloc(n))) return rc;
+    if (first_draw && (rc = d_first.upload(std::vector<uint64_t>(first_draw, first_draw + n)))) return rc;
+    HIP_OK(zr::launch_kat_scatter(s->ds, d_rays.p, d_recs.p, d_keys.p, first_draw ? d_first.p : nullptr, n, d_out.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out, d_out.p, n * sizeof(zr_scatter_out), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+int zr_kat_texture(zr_ctx* c, const zr_scene* s, uint32_t texture_id, const double* uvp5, size_t n, double* out_rgb) {
+    if (!c || !s || (n && (!uvp5 || !out_rgb))) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_kat_texture");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    if (texture_id >= s->textures.size()) return fail(ZR_E_INVALID, "texture id %u out of range", texture_id);
+    if (n == 0) return ZR_OK;
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<double> d_in, d_out;
+    int rc;
+    if ((rc = d_in.upload(std::vector<double>(uvp5, uvp5 + n * 5))) || (rc = d_out.alloc(n * 3))) return rc;
+    HIP_OK(zr::launch_kat_texture(s->ds, texture_id, d_in.p, n, d_out.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out_rgb, d_out.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+int zr_kat_background(zr_ctx* c, const zr_scene* s, const zr_env* env, const double* dirs3, size_t n, double* out_rgb) {
+    if (!c || !s || !env || (n && (!dirs3 || !out_rgb))) return fail(ZR_E_INVALID, "null argument");
+    if (!s->committed) return fail(ZR_E_STATE, "zr_scene_commit must precede zr_kat_background");
+    if (s->ctx != c) return fail(ZR_E_INVALID, "scene belongs to another context");
+    zr::DEnv de; make_env(*env, de);
+    if (de.mode > ZR_ENV_SOLID_COLOR) return fail(ZR_E_INVALID, "unknown environment mode %u", de.mode);
+    if (de.mode == ZR_ENV_HDR_MAP && de.hdr_tex != ZR_NO_TEXTURE && de.hdr_tex >= s->textures.size()) return fail(ZR_E_INVALID, "environment texture id out of range");
+    if (n == 0) return ZR_OK;
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<double> d_in, d_out;
+    int rc;
+    if ((rc = d_in.upload(std::vector<double>(dirs3, dirs3 + n * 3))) || (rc = d_out.alloc(n * 3))) return rc;
+    HIP_OK(zr::launch_kat_background(s->ds, de, d_in.p, n, d_out.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out_rgb, d_out.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+int zr_kat_camera_rays(zr_ctx* c, const zr_camera* cam, uint64_t seed, const int32_t* requests3, size_t n, double* out7) {
+    if (!c || !cam || (n && (!requests3 || !out7))) return fail(ZR_E_INVALID, "null argument");
+    if (n == 0) return ZR_OK;
+    zr::DCamera dc; make_camera(*cam, dc);
+    for (size_t k = 0; k < n; k++)
+        if (requests3[3 * k] < 0 || requests3[3 * k] >= dc.W || requests3[3 * k + 1] < 0 || requests3[3 * k + 1] >= dc.H || requests3[3 * k + 2] < 0)
+            return fail(ZR_E_INVALID, "camera-ray request %zu outside the frame", k);
+    HIP_OK(hipSetDevice(c->device));
+    DevBuf<int32_t> d_req; DevBuf<double> d_out;
+    int rc;
+    if ((rc = d_req.upload(std::vector<int32_t>(requests3, requests3 + n * 3))) || (rc = d_out.alloc(n * 7))) return rc;
+    HIP_OK(zr::launch_kat_camera_rays(dc, seed, d_req.p, n, d_out.p, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out7, d_out.p, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
     return ZR_OK;
 }
 

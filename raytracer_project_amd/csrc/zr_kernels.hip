@@ -279,9 +279,9 @@ __global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* 
     Rng g; g.key = zr_stream_key(seed, pixel, k); g.k = 0; g.bounce = bounce;
     Counters ctr = {0, 0, 0, 0, 0};
     double t; uint32_t kind, idx;
-    bool h = closest_hit<false>(sc, r, tmin, g, lds_stack + threadIdx.x, ZR_BLOCK, t, kind, idx, ctr);
+    bool h = closest_hit<false>(sc, r, tmin, g, lds_stack + threadIdx.x, ZR_BLOCK, t, kind, idx, ctr, tmax);
     zr_hit o;
-    if (h && t < tmax) {
+    if (h) {
         Rec rec;
         object_rec(sc, kind, idx, r, t, rec, true);
         o.p[0] = rec.p.x; o.p[1] = rec.p.y; o.p[2] = rec.p.z;
@@ -294,6 +294,57 @@ __global__ __launch_bounds__(ZR_BLOCK) void trace_rays(DScene sc, const double* 
         o.t = 0; o.u = 0; o.v = 0; o.mat = 0xFFFFFFFFu; o.front_face = 0;
     }
     out[k] = o;
+}
+
+// ---- per-function known-answer kernels (zr_kat_*): one thread = one call of the reference's virtual ---------------------
+__global__ __launch_bounds__(ZR_BLOCK) void kat_scatter(DScene sc, const double* __restrict__ rays, const zr_hit* __restrict__ recs,
+                                                         const uint64_t* __restrict__ keys, const uint64_t* __restrict__ first_draw, size_t n,
+                                                         zr_scatter_out* __restrict__ out) {
+    size_t k = (size_t)blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    Ray r; r.o = ld3(rays + k * 6); r.d = ld3(rays + k * 6 + 3);
+    const zr_hit h = recs[k];
+    Rec rec;
+    rec.p = mk(h.p[0], h.p[1], h.p[2]); rec.n = mk(h.normal[0], h.normal[1], h.normal[2]);
+    rec.tan = mk(h.tangent[0], h.tangent[1], h.tangent[2]); rec.bit = mk(h.bitangent[0], h.bitangent[1], h.bitangent[2]);
+    rec.t = h.t; rec.u = h.u; rec.v = h.v; rec.mat = h.mat; rec.front = h.front_face != 0;
+    Rng g; g.key = keys[k]; g.k = first_draw ? first_draw[k] : 0; g.bounce = 0;
+    const uint64_t k0 = g.k;
+    V3 att = mk(0, 0, 0); Ray nr; nr.o = mk(0, 0, 0); nr.d = mk(0, 0, 0);
+    const V3 em = emitted(sc, rec);                         // material::emitted, material.hpp:12-14,261-263
+    const bool ok = scatter(sc, r, rec, att, nr, g);        // material::scatter
+    zr_scatter_out o;
+    o.attenuation[0] = att.x; o.attenuation[1] = att.y; o.attenuation[2] = att.z;
+    o.origin[0] = nr.o.x; o.origin[1] = nr.o.y; o.origin[2] = nr.o.z;
+    o.direction[0] = nr.d.x; o.direction[1] = nr.d.y; o.direction[2] = nr.d.z;
+    o.emitted[0] = em.x; o.emitted[1] = em.y; o.emitted[2] = em.z;
+    o.scattered = ok ? 1u : 0u; o.draws = (uint32_t)(g.k - k0);
+    if (!ok) for (int c = 0; c < 3; c++) { o.attenuation[c] = 0; o.origin[c] = 0; o.direction[c] = 0; }
+    out[k] = o;
+}
+
+__global__ __launch_bounds__(ZR_BLOCK) void kat_texture(DScene sc, uint32_t tex, const double* __restrict__ uvp, size_t n, double* __restrict__ out) {
+    size_t k = (size_t)blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const V3 c = tex_value(sc, tex, uvp[k * 5], uvp[k * 5 + 1], mk(uvp[k * 5 + 2], uvp[k * 5 + 3], uvp[k * 5 + 4]));   // texture::value
+    out[k * 3] = c.x; out[k * 3 + 1] = c.y; out[k * 3 + 2] = c.z;
+}
+
+__global__ __launch_bounds__(ZR_BLOCK) void kat_background(DScene sc, DEnv env, const double* __restrict__ dirs, size_t n, double* __restrict__ out) {
+    size_t k = (size_t)blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const V3 c = background(sc, env, ld3(dirs + k * 3));     // camera::get_background_color
+    out[k * 3] = c.x; out[k * 3 + 1] = c.y; out[k * 3 + 2] = c.z;
+}
+
+__global__ __launch_bounds__(ZR_BLOCK) void kat_camera_rays(DCamera cam, uint64_t seed, const int32_t* __restrict__ req, size_t n, double* __restrict__ out) {
+    size_t k = (size_t)blockIdx.x * ZR_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const int px = req[k * 3], py = req[k * 3 + 1], smp = req[k * 3 + 2];
+    Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)smp); g.k = 0; g.bounce = 0;
+    const Ray r = camera_ray(cam, px, py, g);               // camera::get_ray
+    out[k * 7] = r.o.x; out[k * 7 + 1] = r.o.y; out[k * 7 + 2] = r.o.z; out[k * 7 + 3] = r.d.x; out[k * 7 + 4] = r.d.y; out[k * 7 + 5] = r.d.z;
+    out[k * 7 + 6] = (double)g.k;
 }
 
 // ---- known-answer kernel for whole paths: one thread walks one primary sample and records every segment ------------
@@ -384,6 +435,28 @@ hipError_t launch_path_records(const DScene& sc, const DCamera& cam, uint64_t se
                                hipStream_t stream) {
     if (n_req <= 0) return hipSuccess;
     hipLaunchKernelGGL(path_records, dim3((unsigned)((n_req + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, sc, cam, seed, req, n_req, max_seg, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_kat_scatter(const DScene& sc, const double* rays, const zr_hit* recs, const uint64_t* keys, const uint64_t* first_draw, size_t n,
+                              zr_scatter_out* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kat_scatter, dim3((unsigned)((n + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, sc, rays, recs, keys, first_draw, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_kat_texture(const DScene& sc, uint32_t tex, const double* uvp, size_t n, double* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kat_texture, dim3((unsigned)((n + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, sc, tex, uvp, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_kat_background(const DScene& sc, const DEnv& env, const double* dirs, size_t n, double* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kat_background, dim3((unsigned)((n + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, sc, env, dirs, n, out);
+    return hipGetLastError();
+}
+hipError_t launch_kat_camera_rays(const DCamera& cam, uint64_t seed, const int32_t* req, size_t n, double* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kat_camera_rays, dim3((unsigned)((n + ZR_BLOCK - 1) / ZR_BLOCK)), dim3(ZR_BLOCK), 0, stream, cam, seed, req, n, out);
     return hipGetLastError();
 }
 

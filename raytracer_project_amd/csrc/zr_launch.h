@@ -36,17 +36,18 @@ struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 exten
     virtual ~StreamTimer() = default;
 };
 #define ST_MAX_POOLS 8   /* sub-pools of the slot pool, one HIP stream each */
-size_t stream_overflow_bytes(int blocks);
+uint32_t stream_overflow_levels(uint32_t stack_demand);
+size_t stream_overflow_bytes(int blocks, uint32_t levels);
 size_t stream_ctl_words();
 int stream_extend_blocks();
 size_t stream_pool_bytes(uint32_t P);
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
-                         uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
+                         uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode = 0, void* d_kend = nullptr,
                          void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
-                        void* pool, unsigned int* d_ctl, void* d_overflow, int extend_blocks, unsigned long long* gctr, bool generic,
+                        void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, bool generic,
                         hipStream_t stream);
 hipError_t launch_aov(const DScene& sc, const DCamera& cam, uint64_t seed, const WorkDesc& wd, int aux, double zmax, const double* uvw9,
                       double* out_albedo, double* out_normal, double* out_zdepth, hipStream_t stream);
@@ -58,6 +59,11 @@ hipError_t launch_analyze(const double* d_frame, size_t n, double* d_part_log, f
 #define ZR_PATH_REC 17
 hipError_t launch_path_records(const DScene& sc, const DCamera& cam, uint64_t seed, const int32_t* req, int n_req, int max_seg, double* out,
                                hipStream_t stream);
+hipError_t launch_kat_scatter(const DScene& sc, const double* rays, const zr_hit* recs, const uint64_t* keys, const uint64_t* first_draw, size_t n,
+                              zr_scatter_out* out, hipStream_t stream);
+hipError_t launch_kat_texture(const DScene& sc, uint32_t tex, const double* uvp, size_t n, double* out, hipStream_t stream);
+hipError_t launch_kat_background(const DScene& sc, const DEnv& env, const double* dirs, size_t n, double* out, hipStream_t stream);
+hipError_t launch_kat_camera_rays(const DCamera& cam, uint64_t seed, const int32_t* req, size_t n, double* out, hipStream_t stream);
 hipError_t launch_trace(const DScene& sc, const double* rays, size_t n, double tmin, double tmax, uint64_t seed, uint64_t pixel,
                         uint32_t bounce, zr_hit* out, hipStream_t stream);
 

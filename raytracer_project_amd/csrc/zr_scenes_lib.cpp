@@ -20,6 +20,7 @@ struct handle {
     zr_scene_desc desc{};
     zr_env env{};
     std::string warnings;
+    std::vector<uint32_t> kat_tex;   // flattened ids of zr_demo_scene::kat_textures
 };
 }  // namespace
 
@@ -32,6 +33,7 @@ void* zrs_build(const char* name, int a0, int a1, int a2, int a3) {
     zenith::scene_builder b(h->fs);
     h->s.world.flatten(b);
     h->env = zenith::to_zr_env(h->s.env, b);
+    for (const auto& t : h->s.kat_textures) h->kat_tex.push_back(b.texture_id(t));
     h->desc = h->fs.desc();
     for (const auto& w : h->fs.warnings) { h->warnings += w; h->warnings += "\n"; }
     for (const auto& f : h->s.temp_files) ::unlink(f.c_str());
@@ -44,6 +46,11 @@ const zr_camera* zrs_camera(void* p) { return &((handle*)p)->s.cam; }
 const zr_env* zrs_env(void* p) { return &((handle*)p)->env; }
 uint64_t zrs_seed(void* p) { return ((handle*)p)->s.seed; }
 const char* zrs_warnings(void* p) { return ((handle*)p)->warnings.c_str(); }
+int zrs_kat_textures(void* p, uint32_t* ids, int cap) {
+    const handle* h = (const handle*)p;
+    for (int k = 0; k < cap && k < (int)h->kat_tex.size(); k++) ids[k] = h->kat_tex[k];
+    return (int)h->kat_tex.size();
+}
 
 // Renders through the drop-in C++ API exactly as the reference's caller does.  out = W*H*3 doubles.
 // spp/width/height <= 0 keep the scene's values.  Returns 0, or -1 if the accumulator stayed empty.
@@ -101,6 +108,52 @@ int zrs_dropin_frame_to_rgb8(void* p, int spp, int device, unsigned char* rgb8, 
     std::memcpy(rgb8, a.data(), a.size());
     std::memcpy(refl8, b.data(), b.size());
     if (exposure_out) *exposure_out = post.exposure;
+    return 0;
+}
+
+// The reference's per-ray virtual API through the drop-in classes: for n rays (o, d, tmin, tmax) calls
+// bvh_node(world).hit(r, interval(tmin, tmax), rec), then rec.mat->emitted(...) and rec.mat->scatter(r, rec, att, scattered)
+// with random_double() positioned on the stream (seed, pixel, k) — the layout of `zenith_ref kat <scene> hits`:
+// recs n x 16 (hit, t, p, normal, front_face, u, v, tangent, first-seen material ordinal, 0), scat n x 14 (scattered, attenuation,
+// origin, direction, emitted, draws).  Returns 0, or -1 when a call threw.
+int zrs_dropin_virtuals(void* p, const double* rays8, int n, uint64_t seed, uint64_t pixel, double* recs16, double* scat14) {
+    handle* h = (handle*)p;
+    try {
+        auto world = make_shared<bvh_node>(h->s.world);
+        std::unordered_map<const material*, int> ordinal;
+        for (int k = 0; k < n; k++) {
+            const double* q = rays8 + (size_t)k * 8;
+            double* e = recs16 + (size_t)k * 16; double* sc = scat14 + (size_t)k * 14;
+            for (int c = 0; c < 16; c++) e[c] = 0;
+            for (int c = 0; c < 14; c++) sc[c] = 0;
+            ray r(point3(q[0], q[1], q[2]), vec3(q[3], q[4], q[5]));
+            zenith::seed_rng(seed, pixel, (uint64_t)k);
+            hit_record rec;
+            if (!world->hit(r, interval(q[6], q[7]), rec)) continue;
+            zenith::seed_rng(seed, pixel, (uint64_t)k);
+            e[0] = 1; e[1] = rec.t; e[2] = rec.p.x(); e[3] = rec.p.y(); e[4] = rec.p.z();
+            e[5] = rec.normal.x(); e[6] = rec.normal.y(); e[7] = rec.normal.z(); e[8] = rec.front_face ? 1 : 0; e[9] = rec.u; e[10] = rec.v;
+            e[11] = rec.tangent.x(); e[12] = rec.tangent.y(); e[13] = rec.tangent.z();
+            if (!rec.mat) { e[14] = -1; continue; }
+            auto it = ordinal.find(rec.mat.get());
+            if (it == ordinal.end()) { const int id = (int)ordinal.size(); ordinal[rec.mat.get()] = id; e[14] = id; } else e[14] = it->second;
+            color em = rec.mat->emitted(rec.u, rec.v, rec.p);
+            ray scattered; color att;
+            const uint64_t k0 = zenith::rng_state().k;
+            bool ok = rec.mat->scatter(r, rec, att, scattered);
+            sc[0] = ok ? 1 : 0;
+            if (ok) {
+                sc[1] = att.x(); sc[2] = att.y(); sc[3] = att.z();
+                sc[4] = scattered.origin().x(); sc[5] = scattered.origin().y(); sc[6] = scattered.origin().z();
+                sc[7] = scattered.direction().x(); sc[8] = scattered.direction().y(); sc[9] = scattered.direction().z();
+            }
+            sc[10] = em.x(); sc[11] = em.y(); sc[12] = em.z();
+            sc[13] = (double)(zenith::rng_state().k - k0);
+        }
+    } catch (const std::exception& ex) {
+        std::cerr << "[zrs_dropin_virtuals] " << ex.what() << "\n";
+        return -1;
+    }
     return 0;
 }
 

@@ -41,14 +41,13 @@ namespace zr {
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
 #ifndef ST_BIAS_NODE
-#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF; favouring LEAF 2:1 is 3 % faster on cfg3 (a tested leaf shrinks tbest and culls the stack), 1:1 and 3:1 are slower */
-#define ST_BIAS_LEAF 2
+#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF */
+#define ST_BIAS_LEAF 1
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
 #define ST_LDS_STACK 12
 #endif
-#define ST_OVERFLOW (ZR_STACK_DEPTH - ST_LDS_STACK)
 
 enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18,
        F_LZERO = 1u << 19 /* SF_L not written yet: it is (0,0,0) */, F_BONE = 1u << 20 /* SF_BETA not written yet: it is (1,1,1) */ };  // meta.y: bounce | b_inner << 8 | flags (F_L0: SF_SUM holds the primary hit's emission)
@@ -127,7 +126,6 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 // relative part lowers the entry distance and raises the exit distance by |t| 2^-20.  An axis whose 1/d or o/d
 // leaves the float range gets id = 0, c = NaN: its planes evaluate to NaN, which fminf/fmaxf ignore, i.e. the slab
 // is dropped (conservative).
-enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2 };
 #define X_LEAF_BIT ZR_REF_LEAF
 
 __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32_t& rb) {
@@ -137,20 +135,30 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
     ta = t0; tb = t1; ra = r0; rb = r1;
 }
 
+// Lane state.  A lane works on up to TWO things at once: a current inner node (`hn`, `cur`) and one POSTPONED leaf (`hl`,
+// `lf`, `pend_i`).  A lane that reaches a leaf does not wait for the next LEAF phase: it parks the leaf and goes on walking
+// the next-nearest subtree, so it keeps taking part in NODE phases, and by the time a LEAF phase runs most lanes hold a
+// leaf (Aila & Laine's postponed leaf test).  With one state per lane the NODE phases of cfg3 ran with 30 of 64 lanes
+// and the LEAF phases with 26; the price is a few node visits that an earlier leaf hit would have culled.  A lane that
+// meets a second leaf while one is parked leaves it on the stack and waits for a LEAF phase ("blocked": !hn, hl, the top
+// of its stack is a leaf).  Idle = !hn && !hl, which implies an empty stack.
 // GENERIC = false: the world holds only bare triangles and spheres (no cubes, media or wrapped objects), so the
 // code for those leaf kinds — and the registers it needs — is compiled out (cfg2, cfg3).
+// Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
+// host sizes the slab from the exact worst-case demand of the committed tree (Flattener::stack_demand), so no push can
+// leave it.
 template <bool COUNT, bool GENERIC>
 __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
-                                                                  unsigned long long* __restrict__ gctr) {
+                                                                  uint32_t ovf_levels, unsigned long long* __restrict__ gctr) {
     __shared__ SEntry lstack[ST_LDS_STACK * 64];
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    SEntry* gstack = overflow + (size_t)blockIdx.x * ST_OVERFLOW * 64 + lane;
+    SEntry* gstack = overflow + (size_t)blockIdx.x * ovf_levels * 64 + lane;
     const double INF = __builtin_huge_val();
     const float INFf = __builtin_huge_valf();
     const uint32_t NONE = 0xFFFFFFFFu;
 
-    int st = X_IDLE;
+    bool hn = false, hl = false;
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     float idx_ = 0, idy_ = 0, idz_ = 0;
@@ -158,8 +166,9 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     double tbest = INF;
     float tbest_f = INFf;
     uint32_t kbest = NONE, ibest = 0;
-    uint32_t cur = 0;       // X_NODE: quad index; X_LEAF: leaf reference (kind << 28 | (count - 1) << 24 | first)
-    uint32_t pend_i = 0;
+    uint32_t cur = 0;       // hn: quad index
+    uint32_t lf = 0;        // hl: leaf reference (kind << 28 | (count - 1) << 24 | first)
+    uint32_t pend_i = 0;    // hl: primitives of lf already tested
     int sp = 0;
     Rng g; g.key = 0; g.k = 0; g.bounce = 0;  // only the medium test reads it
     bool work_left = true;
@@ -174,7 +183,6 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         uint2 ki; ki.x = kbest; ki.y = ibest;
         B.st2(SF_HIT_KI, slot, ki);
         if (COUNT && kbest != NONE) c_hits++;
-        st = X_IDLE;
     };
 // stack helpers are macros, not lambdas: a lambda capturing the __shared__ array by reference turns its accesses into
 // flat-pointer accesses (and trips an LLVM verifier error on gfx950)
@@ -185,14 +193,18 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         if (sp < ZR_LDS_LEVELS) lstack[sp * 64 + lane] = e_; else gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64] = e_; \
         sp++;                                                                                                   \
     }
-// nearest deferred entry that can still matter, else the ray is done
-#define ZR_POP_NEXT()                                                                                           \
+// the lane has no current node: take work off its stack, nearest first.  Entries beyond the current hit are dropped
+// without a fetch; an inner node becomes the current node; a leaf is parked if the leaf slot is free (and the search
+// goes on), else it stays on the stack and the lane waits for a LEAF phase.  Nothing left at all: the ray is done.
+#define ZR_ADVANCE()                                                                                            \
     for (;;) {                                                                                                  \
-        if (sp == 0) { finish(); break; }                                                                       \
-        sp--;                                                                                                   \
+        if (sp == 0) { if (!hl) finish(); break; }                                                              \
         SEntry e_;                                                                                              \
-        if (sp < ZR_LDS_LEVELS) e_ = lstack[sp * 64 + lane]; else e_ = gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64]; \
-        if (e_.tn <= tbest_f) { cur = e_.node; pend_i = 0; st = (e_.node & X_LEAF_BIT) ? X_LEAF : X_NODE; break; } \
+        if (sp <= ZR_LDS_LEVELS) e_ = lstack[(sp - 1) * 64 + lane]; else e_ = gstack[(size_t)(sp - 1 - ZR_LDS_LEVELS) * 64]; \
+        if (!(e_.tn <= tbest_f)) { sp--; continue; }                                                            \
+        if (!(e_.node & X_LEAF_BIT)) { sp--; cur = e_.node; hn = true; break; }                                 \
+        if (hl) break;                                                                                          \
+        sp--; lf = e_.node; pend_i = 0; hl = true;                                                              \
     }
 
 // one child from the parametric distances of its six planes (absolute slack already inside): entry distance or +inf
@@ -212,15 +224,20 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #define ZR_FBOX(N, C, TN, RF)                                                                               \
     ZR_SLAB(fmaf((N).lox[C], idx_, clx), fmaf((N).hix[C], idx_, chx), fmaf((N).loy[C], idy_, cly), fmaf((N).hiy[C], idy_, chy), \
             fmaf((N).loz[C], idz_, clz), fmaf((N).hiz[C], idz_, chz), (N).ref[C], TN, RF)
-// the four children by entry distance (5-comparator network): push far -> near, continue with the nearest
+// the four children by entry distance (5-comparator network): push far -> near, continue with the nearest.  A nearest
+// child that is a leaf is parked (and the lane goes on with the next entry) or, if a leaf is parked already, pushed too.
 #define ZR_DESCEND()                                                                                        \
     {                                                                                                       \
         cswap(tn0, r0, tn1, r1); cswap(tn2, r2, tn3, r3); cswap(tn0, r0, tn2, r2); cswap(tn1, r1, tn3, r3); cswap(tn1, r1, tn2, r2); \
+        hn = false;                                                                                         \
         if (tn3 < INFf) ZR_PUSH(r3, tn3)                                                                    \
         if (tn2 < INFf) ZR_PUSH(r2, tn2)                                                                    \
         if (tn1 < INFf) ZR_PUSH(r1, tn1)                                                                    \
-        if (tn0 < INFf) { cur = r0; pend_i = 0; st = (r0 & X_LEAF_BIT) ? X_LEAF : X_NODE; }                 \
-        else { ZR_POP_NEXT() }                                                                              \
+        if (tn0 < INFf) {                                                                                   \
+            if (!(r0 & X_LEAF_BIT)) { cur = r0; hn = true; }                                                \
+            else if (!hl) { lf = r0; pend_i = 0; hl = true; ZR_ADVANCE() }                                  \
+            else ZR_PUSH(r0, tn0)                                                                           \
+        } else { ZR_ADVANCE() }                                                                             \
     }
 
     const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
@@ -230,19 +247,19 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     unsigned long long p_exec[3] = {0, 0, 0}, p_lanes[3] = {0, 0, 0};
 #endif
     for (; iter < iter_cap; iter++) {
-        const uint32_t lkind = (cur >> 28) & 7u;
-        const int n1 = __popcll(__ballot(st == X_NODE));
-        const int n2t = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_TRIANGLE));
-        const int n2s = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_SPHERE));
-        const int n2g = GENERIC ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
-        const int n0 = work_left ? __popcll(__ballot(st == X_IDLE)) : 0;
+        const uint32_t lkind = (lf >> 28) & 7u;
+        const int n1 = __popcll(__ballot(hn));
+        const int n2t = __popcll(__ballot(hl && lkind == ZR_PRIM_TRIANGLE));
+        const int n2s = __popcll(__ballot(hl && lkind == ZR_PRIM_SPHERE));
+        const int n2g = GENERIC ? __popcll(__ballot(hl)) - n2t - n2s : 0;
+        const int n0 = work_left ? __popcll(__ballot(!hn && !hl)) : 0;
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
         if (n1 + n2 + n0 == 0) break;
 
         if (n0 >= ST_FETCH_MIN || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
             // ================= FETCH: idle lanes take the next ray indices =================
             // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays
-            const unsigned long long idle = __ballot(st == X_IDLE);
+            const unsigned long long idle = __ballot(!hn && !hl);
             uint32_t n = (uint32_t)__popcll(idle);
 #ifdef ZR_WAVE_PROFILE
             p_exec[2]++; p_lanes[2] += n;
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             const uint32_t base = chunk_next;
             chunk_next += n;
             const uint32_t lim = base + n;
-            if (st == X_IDLE) {
+            if (!hn && !hl) {
                 const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
                 if (my < lim) {
                     const uint2 m = B.ld2(SF_MA, my);
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #ifdef ZR_WAVE_PROFILE
             p_exec[0]++; p_lanes[0] += n1;
 #endif
-            if (st == X_NODE) {
+            if (hn) {
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
                 const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
@@ -334,26 +351,25 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #ifdef ZR_WAVE_PROFILE
             p_exec[1]++; p_lanes[1] += n2;
 #endif
-            const bool is_leaf = st == X_LEAF;
             const bool do_tri = n2t == n2;
             const bool do_sph = !do_tri && n2s == n2;
-            const uint32_t prim = (cur & 0xFFFFFFu) + pend_i;
+            const uint32_t prim = (lf & 0xFFFFFFu) + pend_i;
             bool tested = false;
             if (do_tri) {
-                if (is_leaf && lkind == ZR_PRIM_TRIANGLE) {
+                if (hl && lkind == ZR_PRIM_TRIANGLE) {
                     double t;
                     if (COUNT) c_tri++;
                     if (triangle_t(sc.tri_v + (size_t)prim * 9, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
             } else if (do_sph) {
-                if (is_leaf && lkind == ZR_PRIM_SPHERE) {
+                if (hl && lkind == ZR_PRIM_SPHERE) {
                     double t;
                     if (COUNT) c_sph++;
                     if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
-            } else if (GENERIC && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+            } else if (GENERIC && hl && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
                 if (COUNT) {
                     uint32_t kk = lkind;
@@ -365,7 +381,10 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             }
             if (tested) {
                 pend_i++;
-                if (pend_i > ((cur >> 24) & 0xFu)) { ZR_POP_NEXT() }
+                if (pend_i > ((lf >> 24) & 0xFu)) {
+                    hl = false;
+                    if (!hn) { ZR_ADVANCE() }
+                }
             }
         }
     }
@@ -690,7 +709,9 @@ __global__ __launch_bounds__(256) void stream_hits_out(DScene sc, StreamBuf B, u
 
 // ---- host-side launch helpers -----------------------------------------------------------------------------------
 size_t stream_ctl_words() { return 16 + 32 * ST_SHARDS; }
-size_t stream_overflow_bytes(int blocks) { return (size_t)blocks * ST_OVERFLOW * 64 * sizeof(SEntry); }
+// spill slab of the EXTEND stack: `stack_demand` = worst-case entries of the committed tree (zr_scene_stats), ST_LDS_STACK of them live in LDS
+uint32_t stream_overflow_levels(uint32_t stack_demand) { return stack_demand > ST_LDS_STACK ? stack_demand - ST_LDS_STACK : 1u; }
+size_t stream_overflow_bytes(int blocks, uint32_t levels) { return (size_t)blocks * levels * 64 * sizeof(SEntry); }
 
 int stream_extend_blocks() {
     int dev = 0, cus = 256, per_cu = 16;
@@ -716,9 +737,9 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
 }
 
 template <bool COUNT>
-static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, int blocks, unsigned long long* gctr, bool generic, hipStream_t st) {
-    if (generic) hipLaunchKernelGGL((stream_extend<COUNT, true>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
-    else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, gctr);
+static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, uint32_t ovf_levels, int blocks, unsigned long long* gctr, bool generic, hipStream_t st) {
+    if (generic) hipLaunchKernelGGL((stream_extend<COUNT, true>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
 }
 
 // The slot pool can be split into K sub-pools that run a fraction of a round apart on K HIP streams, so that one
@@ -726,7 +747,7 @@ static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, 
 // 1/8 shard, K >= 3 loses (the stages are throughput-bound, co-running launches only stretch each other).
 // streams[0] is the caller's stream, the others are internal.
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
-                         uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, int extend_blocks,
+                         uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode, void* d_kend, void* d_cls,
                          double* out2, unsigned long long* d_cpart) {
@@ -745,7 +766,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
             Q[k] = make_buf(base, Pk, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + (size_t)k * W, uctl, first, P);
             Q[k].kend = (uint2*)d_kend; Q[k].cls = (unsigned char*)d_cls;
             Q[k].cpart = d_cpart ? d_cpart + ((size_t)first / 256 + (size_t)k) * 4 : nullptr;
-            ov[k] = (unsigned char*)d_overflow + (size_t)k * stream_overflow_bytes(extend_blocks);
+            ov[k] = (unsigned char*)d_overflow + (size_t)k * stream_overflow_bytes(extend_blocks, ovf_levels);
             base += stream_pool_bytes(Pk);
             first += Pk;
         }
@@ -764,7 +785,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     auto extend = [&](const StreamBuf& B, void* o, hipStream_t st) {
         const int eb = (int)((B.P + 63) / 64 < (uint32_t)extend_blocks ? (B.P + 63) / 64 : (uint32_t)extend_blocks);
         if (timer) timer->begin(st, 1);
-        if (count) launch_extend<true>(sc, B, o, eb, gctr, generic, st); else launch_extend<false>(sc, B, o, eb, gctr, generic, st);
+        if (count) launch_extend<true>(sc, B, o, ovf_levels, eb, gctr, generic, st); else launch_extend<false>(sc, B, o, ovf_levels, eb, gctr, generic, st);
         if (timer) timer->end(st, 1);
     };
     auto shade = [&](const StreamBuf& B, hipStream_t st) {
@@ -819,7 +840,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
 
 // closest hits of n rays in [0.001, inf) through the EXTEND kernel; `pool` holds stream_pool_bytes(round_up(n, 64)) bytes
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
-                        void* pool, unsigned int* d_ctl, void* d_overflow, int extend_blocks, unsigned long long* gctr, bool generic,
+                        void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, bool generic,
                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const uint32_t P = (n + 63u) / 64u * 64u;
@@ -829,7 +850,7 @@ hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint
     if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(stream_load_rays, dim3((P + 255) / 256), dim3(256), 0, stream, B, d_rays, n, seed, pixel, bounce);
     const int eb = (int)(P / 64 < (uint32_t)extend_blocks ? P / 64 : (uint32_t)extend_blocks);
-    launch_extend<false>(sc, B, d_overflow, eb, gctr, generic, stream);
+    launch_extend<false>(sc, B, d_overflow, ovf_levels, eb, gctr, generic, stream);
     hipLaunchKernelGGL(stream_hits_out, dim3((n + 255) / 256), dim3(256), 0, stream, sc, B, n, d_out);
     return hipGetLastError();
 }

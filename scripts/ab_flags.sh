@@ -1,9 +1,14 @@
-# development aid: bench the in-tree build, then rebuild the library with extra definitions ("$@", one build each) and bench again
+# development aid: bench the in-tree build, then rebuild the library with extra definitions ("$@", one build each) and bench again.
+# The variants are built into a scratch copy of csrc/ (ZR_LIB points capi at it), so the in-tree library — the one the
+# tests and later steps of the same gpurun call load — is never replaced by an instrumented or experimental build.
 R=$GRAFT_REPO_ROOT
-run() { python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.readline()); print("ms_per_step", d["ms_per_step"], "extend ms/launch", d["roofline"]["kernel_ms"], "per step", d["roofline"]["kernel_ms_per_step"], "checksum", d["config"]["frame_checksum"])'; }
+S=${TMPDIR:-/tmp}/zr_ab_$$
+run() { python3 $R/bench.py --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("ms_per_step", d["ms_per_step"], "extend ms/launch", r["kernel_ms"], "per step", r["kernel_ms_per_step"], "launches", r["launches_timed"], "checksum", d["config"]["frame_checksum"])'; }
 echo "in-tree: $(run)"
+mkdir -p $S/raytracer_project_amd && cp -r $R/include $S/ && cp -r $R/scenes $S/ && cp -r $R/raytracer_project_amd/csrc $S/raytracer_project_amd/
 for f in "$@"; do
-  touch $R/raytracer_project_amd/csrc/*.hip $R/raytracer_project_amd/csrc/*.cpp
-  make -s -C $R/raytracer_project_amd/csrc ZR_DEFS="$f" > /dev/null 2>&1
-  echo "$f: $(run)"
+  touch $S/raytracer_project_amd/csrc/*.hip $S/raytracer_project_amd/csrc/*.cpp
+  make -s -j8 -C $S/raytracer_project_amd/csrc ZR_DEFS="$f" > $S/build.log 2>&1 || { echo "$f: BUILD FAILED"; tail -5 $S/build.log; continue; }
+  echo "$f: $(ZR_LIB=$S/raytracer_project_amd/csrc/libzr_hip.so run)"
 done
+rm -rf $S

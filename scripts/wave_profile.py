@@ -22,6 +22,8 @@ def run(tag, reg):
         tot / waves, 100 * ne / tot, nl / max(1, ne), 100 * le / tot, ll / max(1, le), 100 * fe / tot, fl / max(1, fe), life_ms * 1e3 / tot), flush=True)
 R = capi.Region
 run('full', None)
+if "--full-only" in sys.argv:
+    sys.exit(0)
 run('shard 1/8', R(0, 0, 0, 0, 32, 8, 0, 0))
 run('band sky y0=0', R(0, 0, 1920, 135, 32, 0, 0, 0))
 run('band knot y0=540', R(0, 540, 1920, 135, 32, 0, 0, 0))

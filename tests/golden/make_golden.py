@@ -81,6 +81,128 @@ POSTS = {
 }
 
 
+def kat_inputs():
+    """Hand-placed inputs of the per-function known-answer fixture (scene "kat0", scenes/zr_scenes_mix.inc).
+    rays: (o, d, tmin, tmax); the comment names the reference behaviour each one pins."""
+    INF = float("inf")
+    R = []
+
+    def ray(o, d, tmin=0.001, tmax=INF):
+        R.append(list(o) + list(d) + [tmin, tmax])
+    # sphere::hit (sphere.hpp:18-79): centre (0, 4, 0), r = 1, image-textured
+    ray((0, 4, 5), (0, 0, -1))                       # near root, front face
+    ray((0, 4, 0), (0, 0, -1))                       # origin inside: near root negative, far root taken, back face
+    ray((0, 9, 0), (0, -1, 0))                       # north pole: up x n vanishes -> tangent fallback z x n (sphere.hpp:50-59), v = 1
+    ray((0, 1, 0), (0, 1, 0))                        # south pole, v = 0
+    ray((1e-9, 9, 0), (0, -1, 0))                    # a hair off the pole: the fallback threshold
+    ray((1, 4, 5), (0, 0, -1))                       # tangent ray: discriminant exactly 0
+    ray((0, 4, 5), (0, 0, -1), 0.001, 4.0)           # t == ray_t.max: surrounds() is strict -> miss
+    ray((0, 4, 5), (0, 0, -1), 0.001, 4.000001)
+    ray((0, 4, 5), (0, 0, -1), 4.0, INF)             # t == ray_t.min: strict -> the far root (t = 6)
+    for k in range(8):                               # around the equator: u = (atan2(-z, x) + pi) / 2 pi incl. the seam
+        c, sn = np.cos(k * np.pi / 4), np.sin(k * np.pi / 4)
+        ray((5 * c, 4, 5 * sn), (-5 * c, 0, -5 * sn))          # un-normalised direction: t = 0.8
+    ray((0, 4, 5), (0, 0, -1e-3))                    # short direction vector: t = 4000
+    # cube::hit (cube.hpp:44-142): bare, origin-centred, half extents (1, 0.5, 0.75)
+    ray((3, .1, .2), (-1, 0, 0)); ray((-3, .1, .2), (1, 0, 0)); ray((.3, 3, .2), (0, -1, 0))
+    ray((.3, -2, .2), (0, 1, 0)); ray((.3, .1, 3), (0, 0, -1)); ray((.3, .1, -1.5), (0, 0, 1))
+    ray((0.2, 0.1, -0.1), (1, 0.3, 0.2))             # origin inside: rec.t = ray_t.min, no face matches -> the +z fallthrough
+    ray((3, 0.5, 0), (-1, 0, 0))                     # along the top face plane: 0 * inf = NaN in the y slab, fmax / fmin ignore it
+    ray((3, 3, 3), (-1, -1, -1))
+    ray((3, 0.5000001, 0), (-1, 0, 0))               # just above the face (inside the padded box): miss
+    # dielectric sphere (6, 0, 0)
+    ray((6, 0, 5), (0, 0, -1))
+    ray((6, 0, 0), (0, 0.6, 0.8))                    # from inside, normal incidence: exit IOR
+    ray((6, 0.9, 0), (1, 0, 0))                      # from inside at 64 degrees: total internal reflection, no draw
+    ray((6.95, 0, 5), (0, 0, -1))                    # grazing from outside: Schlick close to 1
+    # metal
+    ray((0, -4, 5), (0, 0, -1))                      # fuzz 0 still draws a unit vector (material.hpp:141)
+    ray((2, -4, 5), (-0.3, 0, -1))
+    ray((6.99, 4, 5), (0, 0, -1))                    # fuzz 0.4 at grazing incidence: scatter may return false
+    ray((6, 4, 5), (0, 0, -1))                       # bump map + nested checker
+    ray((-6, 0, 5), (0, 0, -1))                      # diffuse_light: emitted = texture, scatter false
+    ray((-6, 3, 5), (0, 0, -1))                      # failed image load: cyan
+    ray((-6.1, -3, 5), (0, 0, -1))                   # sphere built with r = -0.75: box from |r|, hit radius max(0, r) = 0 -> miss
+    ray((6, -4, 5), (0, 0, -1)); ray((6.5, -4.3, 5), (0, 0, -1))      # bumped lambertian
+    # triangle::hit (triangle.hpp:17-82): A (3,0,-2) B (5,0,-2) C (3,2,-2), plane z = -2
+    ray((3.5, 0.5, 3), (0, 0, -1))
+    ray((4, 0, 3), (0, 0, -1))                       # on edge AB: the edge test is >= 0
+    ray((3, 0, 3), (0, 0, -1))                       # on vertex A
+    ray((4, 1, 3), (0, 0, -1))                       # on edge BC
+    ray((4, -1e-12, 3), (0, 0, -1))                  # a hair outside
+    ray((3.5, 0.5, 3), (0, 0, -1), 0.001, 5.0)       # t == ray_t.max: contains() is inclusive -> hit
+    ray((3.5, 0.5, 3), (0, 0, -1), 0.001, 4.999999999)
+    ray((3.5, 0.5, 3), (0, 0, -1), 5.0, INF)         # t == ray_t.min: inclusive -> hit
+    ray((3.5, 0.5, -2), (1, 0, 0))                   # in the plane: |N.d| < 1e-8 -> miss
+    ray((3.5, 0.5, -5), (0, 0, 1))                   # back face
+    ray((3.0, 0.5, -1.9999999999), (1, 0, -1e-9))    # geometrically a hit, rejected by the parallel threshold
+    ray((3.5, 0.5, 3), (0, 0, -1e6))                 # t = 5e-6 < ray_t.min
+    ray((1.5, 9, 0), (0, -1, 0))                     # through the degenerate triangle at y = 8: never hit
+    ray((-4, 0.8333, 3), (0, 0, -1)); ray((-4, 0.8333, -6), (0, 0, 1))   # tilted triangle with smooth normals, both sides
+    # cube under translate: front_face forced true (translate.hpp:29)
+    ray((0.1, 0.2, 9), (0, 0, -1)); ray((0, 0, 6), (0, 0, 1))
+    # constant_medium in a sphere (0, 0, -8) r = 2
+    ray((0, 0, -3), (0, 0, -1)); ray((0, 0, -8), (1, 0, 0)); ray((3, 0, -3), (0, 0, -1)); ray((0, 0, -3), (0, 0, -1), 0.001, 4.0)
+    # closest of several, signed zeros, far origin
+    ray((-10, 0, 0), (1, 0, 0)); ray((10, 0, 0), (-1, 0, 0)); ray((0, 4, 5), (-0.0, 0.0, -1)); ray((0, 4, 1e6), (0, 0, -1))
+    rays = np.array(R, dtype=np.float64)
+
+    # texture::value: every kat texture at and beyond the edges of the unit square
+    edge = [0.0, 1.0, -0.25, 1.25, 0.5, 0.999999, 1e-9, 2.5, -3.75, 0.0625, 0.9375]
+    pts = [(0, 0, 0), (0.5, 0, 0), (-0.5, 0.25, 1.5), (1.4999999, -1.5, 0.7), (-1e-12, 3.0, -0.75)]
+    T = [[t, u, v, *pts[(iu + 3 * iv + t) % len(pts)]] for t in range(6) for iu, u in enumerate(edge) for iv, v in enumerate(edge)]
+    tex = np.array(T, dtype=np.float64)
+
+    # get_background_color: mode, bg rgb, intensity, yaw, tilt, roll, sun dir, sun colour, sun intensity, sun size | direction
+    s0 = np.array([1.0, 0.5, -0.5]) / np.linalg.norm([1.0, 0.5, -0.5])
+    envs = [
+        [0, 0, 0, 0, 1.0, 0, 0, 0, *s0, 1, 1, 1, 1.0, 1.0],                       # the default PHYSICAL_SUN
+        [0, 0, 0, 0, 0.8, 0, 0, 0, 1.0, 0.06, -0.45, 1, 0.9, 0.8, 3.0, 8.0],      # low sun: sunset branch, not normalised
+        [0, 0, 0, 0, 1.3, 0, 0, 0, 1.0, -0.02, -0.3, 1, 1, 1, 2.0, 4.0],          # sun just below the horizon
+        [0, 0, 0, 0, 1.0, 0, 0, 0, 1.0, -0.5, 0.0, 1, 1, 1, 1.0, 1.0],            # night: no disc
+        [2, 0.25, 0.3, 0.35, 1.2, 0, 0, 0, *s0, 1, 1, 1, 1.0, 1.0],               # SOLID_COLOR
+        [1, 0, 0, 0, 0.75, 1.1, 0.35, -0.4, *s0, 1, 1, 1, 1.0, 1.0],              # HDR_MAP, yaw / tilt / roll
+        [1, 0, 0, 0, 1.0, 0, 0, 0, *s0, 1, 1, 1, 1.0, 1.0],                       # HDR_MAP, no rotation: poles and the seam
+    ]
+    rng = np.random.default_rng(20261004)
+    dirs = [(0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, 0, -1), (1, 1e-12, 0), (1, -1e-12, 0), (-1, 0, 1e-12), (-1, 0, -1e-12),
+            (3, 4, 0), (0.001, 0.002, 0.002)]
+    dirs += [tuple(v) for v in rng.normal(size=(20, 3))]
+    B = []
+    for e in envs:
+        sun = np.array(e[8:11]) / np.linalg.norm(e[8:11])
+        mine = list(dirs)
+        if e[0] == 0:   # at, inside and across the edge of the sun disc (threshold 1 - sun_size / 1000, smoothstep 2e-4 wide)
+            thr = 1.0 - e[15] * 0.001
+            ortho = np.cross(sun, [0.3, 0.1, 0.9]); ortho /= np.linalg.norm(ortho)
+            for cosang in (1.0, thr + 0.0003, thr + 0.0001, thr + 0.00005, thr - 0.00001):
+                mine.append(tuple(cosang * sun + np.sqrt(max(0.0, 1 - cosang * cosang)) * ortho))
+        B += [e + list(d) for d in mine]
+    bg = np.array(B, dtype=np.float64)
+    cam = {"kat0": np.array([[i, j, s] for (i, j) in [(0, 0), (63, 0), (0, 47), (63, 47), (31, 23)] for s in range(4)], dtype=np.float64),
+           "cfg1": np.array([[i, j, s] for (i, j) in [(0, 0), (399, 0), (0, 224), (399, 224), (200, 112)] for s in range(2)], dtype=np.float64)}
+    return rays, tex, bg, cam
+
+
+def make_kat(tmp):
+    rays, tex, bg, cam = kat_inputs()
+    arrays, metas = {"rays": rays, "tex_in": tex, "bg_in": bg}, {}
+    for what, arr, outs in (("hits", rays, ("recs", "scat")), ("tex", tex, ("rgb",)), ("bg", bg, ("rgb",))):
+        f = os.path.join(tmp, f"kat_{what}.bin"); pre = os.path.join(tmp, f"kat_{what}")
+        arr.tofile(f)
+        metas[what] = run("kat", "kat0", what, f, len(arr), pre)
+        for o in outs:
+            arrays[f"{what}_{o}" if what != "hits" else o] = np.load(f"{pre}_{o}.npy")
+    for scene, req in cam.items():
+        f = os.path.join(tmp, f"kat_cam_{scene}.bin"); pre = os.path.join(tmp, f"kat_cam_{scene}")
+        req.tofile(f)
+        metas[f"cam_{scene}"] = run("kat", scene, "cam", f, len(req), pre)
+        arrays[f"cam_req_{scene}"] = req.astype(np.int32)
+        arrays[f"cam_rays_{scene}"] = np.load(pre + "_rays.npy")
+    np.savez_compressed(os.path.join(HERE, "kat_kat0.npz"), meta=np.array(json.dumps(metas)), **arrays)
+    print("kat_kat0", {k: v.shape for k, v in arrays.items()})
+
+
 def run(*args):
     p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -151,6 +273,8 @@ def main():
                 arrays["hist"] = np.load(pre + "_hist.npy")
             np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(json.dumps(metas)), **arrays)
             print(name, [m["preset"] for m in metas])
+        if not want or "kat" in want or "kat0" in want:
+            make_kat(tmp)
         if not want or "texels" in want:
             out = os.path.join(tmp, "texels.npy")
             subprocess.run([REF, "texels", "64", "32", out], check=True)

@@ -48,9 +48,12 @@ def _check(tile, want, what):
     return float(err.max())
 
 
+@pytest.mark.parametrize("count", [False, True], ids=["timed", "counting"])
 @pytest.mark.parametrize("name", TILE_FIXTURES)
-def test_radiance_matches_reference(name, ctx):
-    """GPU radiance vs the genuine reference's, same scene / camera / seed / spp."""
+def test_radiance_matches_reference(name, count, ctx):
+    """GPU radiance vs the genuine reference's, same scene / camera / seed / spp — through BOTH instantiations of the
+    pipeline kernels: the uninstrumented one bench.py times (`count=False`) and the counting one, whose segment and
+    RNG-draw totals must equal the reference's exactly."""
     from raytracer_project_amd import capi
     fx = load_golden(name)
     m = fx["meta"]
@@ -59,14 +62,15 @@ def test_radiance_matches_reference(name, ctx):
     cam.samples_per_pixel = m["spp"]
     reg = capi.Region(m["x0"], m["y0"], m["w"], m["h"], 0, 0, 0, 0)
     sc = gpu_scene(ctx, m["scene"], m["scene_args"])
-    out = sc.render(cam, ds.env, ds.seed, reg, count=True)
+    out = sc.render(cam, ds.env, ds.seed, reg, count=count)
     ctr = ctx.counters()
     tile = out[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]]
     worst = _check(tile, fx["mean"], name)
-    # integer work accounting is bit-exact: same number of closest-hit queries and of RNG draws
-    assert ctr.primary_samples == m["w"] * m["h"] * m["spp"]
-    assert ctr.segments == m["segments"], (ctr.segments, m["segments"])
-    assert ctr.rng_draws == m["draws"], (ctr.rng_draws, m["draws"])
+    if count:
+        # integer work accounting is bit-exact: same number of closest-hit queries and of RNG draws
+        assert ctr.primary_samples == m["w"] * m["h"] * m["spp"]
+        assert ctr.segments == m["segments"], (ctr.segments, m["segments"])
+        assert ctr.rng_draws == m["draws"], (ctr.rng_draws, m["draws"])
     # pixels outside the region are untouched (integer pixel indexing)
     mask = np.ones(out.shape[:2], bool)
     mask[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]] = False
@@ -112,6 +116,88 @@ def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     assert len(pairs) == len({a for a, _ in pairs}) == len({b for _, b in pairs})
 
 
+@pytest.mark.parametrize("engine", ["extend", "pairs"])
+def test_known_answers_on_hand_placed_inputs(engine, ctx, monkeypatch):
+    """Per-function known answers (tests/golden/kat_kat0.npz, generated by the genuine reference functions): sphere / triangle /
+    cube / medium ::hit at their edge cases (poles, tangent rays, edge and vertex hits, t == ray_t.min / max with each
+    primitive's own open / closed reading, origin inside the cube, the parallel threshold, a negative radius), material::scatter
+    + emitted on those hits (fuzz-0 metal, total internal reflection, both faces, absorbed metal, light, failed texture load),
+    texture::value at and beyond the unit square, get_background_color in every mode (disc edge, poles, seam), and get_ray at the
+    corners of the frame — on the device, through zr_trace / zr_kat_*.  Decisions and draw counts exact, values to 1e-12."""
+    from test_oracle_golden import kat_env, kat_trace
+    from oracle import zr_oracle_py as zo
+    monkeypatch.setenv("ZR_TRACE_ENGINE", engine)
+    fx = load_golden("kat_kat0")
+    m = fx["meta"]["hits"]
+    ds = demo_scene("kat0")
+    sc = gpu_scene(ctx, "kat0")
+    rays, recs, scat = fx["rays"], fx["recs"], fx["scat"]
+    if engine == "extend":   # the EXTEND kernel answers the render interval only
+        keep = (rays[:, 6] == 0.001) & np.isinf(rays[:, 7])
+        hits = np.zeros(len(rays), dtype=sc.trace(rays[:1, :6]).dtype)
+        hits[:] = sc.trace(rays[:, :6], 0.001, float("inf"), seed=m["seed"], pixel=m["stream_pixel"], bounce=0)
+    else:
+        keep = np.ones(len(rays), bool)
+        hits = kat_trace(lambda r, a, b: sc.trace(r, a, b, seed=m["seed"], pixel=m["stream_pixel"], bounce=0), rays)
+    ref_hit = recs[:, 0] > 0
+    got_hit = hits["mat"] != 0xFFFFFFFF
+    assert np.array_equal(ref_hit[keep], got_hit[keep]), np.flatnonzero(keep & (ref_hit != got_hit))
+    h = ref_hit & keep
+    tol = 1e-12
+
+    def close(a, b, what):
+        err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+        assert err.max() <= tol, f"{what}: max error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    close(hits["t"][h], recs[h, 1], "t"); close(hits["p"][h], recs[h, 2:5], "p"); close(hits["normal"][h], recs[h, 5:8], "normal")
+    assert np.array_equal(hits["front_face"][h], recs[h, 8].astype(np.uint32))
+    close(hits["u"][h], recs[h, 9], "u"); close(hits["v"][h], recs[h, 10], "v"); close(hits["tangent"][h], recs[h, 11:14], "tangent")
+    pairs = set(zip(recs[h, 14].astype(int).tolist(), hits["mat"][h].tolist()))
+    assert len(pairs) == len({a for a, _ in pairs}) == len({b for _, b in pairs})
+    keys = np.array([zo.stream_key(m["seed"], m["stream_pixel"], k) for k in range(len(rays))], dtype=np.uint64)
+    so = sc.kat_scatter(rays[h, :6], hits[h], keys[h])
+    assert np.array_equal(so["scattered"], scat[h, 0].astype(np.uint32))
+    assert np.array_equal(so["draws"], scat[h, 13].astype(np.uint32))
+    close(so["attenuation"], scat[h, 1:4], "attenuation"); close(so["origin"], scat[h, 4:7], "scattered origin")
+    close(so["direction"], scat[h, 7:10], "scattered direction"); close(so["emitted"], scat[h, 10:13], "emitted")
+    if engine == "pairs":   # the remaining entry points do not depend on the traversal engine
+        tin = fx["tex_in"]
+        for t in range(6):
+            sel = tin[:, 0] == t
+            close(sc.kat_texture(ds.kat_textures[t], tin[sel, 1:6]), fx["tex_rgb"][sel], f"texture {t}")
+        bin_ = fx["bg_in"]
+        for env_row in {tuple(r[:16]) for r in bin_}:
+            sel = np.all(bin_[:, :16] == np.array(env_row), axis=1)
+            close(sc.kat_background(kat_env(env_row, ds.env.hdr_texture), bin_[sel, 16:19]), fx["bg_rgb"][sel], f"environment {env_row[:5]}")
+        for scene in ("kat0", "cfg1"):
+            d2 = demo_scene(scene)
+            got = ctx.kat_camera_rays(d2.camera, d2.seed, fx[f"cam_req_{scene}"])
+            close(got[:, :6], fx[f"cam_rays_{scene}"][:, :6], f"get_ray {scene}")
+            assert np.array_equal(got[:, 6], fx[f"cam_rays_{scene}"][:, 6])
+
+
+def test_dropin_virtuals_are_callable(ctx):
+    """hittable::hit (hittable.hpp:29-36) and material::scatter / emitted (material.hpp:7-31) of the drop-in's built-in classes
+    stay callable: bvh_node(world).hit(r, interval, rec) and rec.mat->scatter(...) called from C++ against include/zenith/zenith.hpp
+    — each call one ray through the device — reproduce the genuine reference's answers on the hand-placed inputs."""
+    fx = load_golden("kat_kat0")
+    m = fx["meta"]["hits"]
+    ds = demo_scene("kat0")
+    rays, recs, scat = fx["rays"], fx["recs"], fx["scat"]
+    got_r, got_s = ds.dropin_virtuals(rays, m["seed"], m["stream_pixel"])
+    h = recs[:, 0] > 0
+    assert np.array_equal(got_r[:, 0] > 0, h)
+    medium = h & (recs[:, 5] == 1) & (recs[:, 6] == 0) & (recs[:, 7] == 0) & (recs[:, 9] == 0) & (recs[:, 11] == 0) & (np.abs(rays[:, 2]) >= 3) & (rays[:, 1] == 0)
+    assert 2 <= medium.sum() <= 4   # constant_medium::hit draws off-stream: the callable hit() keys it by the host stream position
+    x = h & ~medium
+    err = np.abs(got_r[x, 1:14] - recs[x, 1:14]) / np.maximum(1.0, np.abs(recs[x, 1:14]))
+    assert err.max() <= 1e-12, err.max()
+    pairs = set(zip(recs[x, 14].astype(int).tolist(), got_r[x, 14].astype(int).tolist()))
+    assert len(pairs) == len({a for a, _ in pairs}) == len({b for _, b in pairs})
+    assert np.array_equal(got_s[x, 0], scat[x, 0]) and np.array_equal(got_s[x, 13], scat[x, 13])   # scattered flag, draws consumed
+    err = np.abs(got_s[x, 1:13] - scat[x, 1:13]) / np.maximum(1.0, np.abs(scat[x, 1:13]))
+    assert err.max() <= 1e-12, err.max()
+
+
 @pytest.mark.parametrize("name", ["cfg3_small", "cfg2", "mix0"])
 def test_extend_adversarial_rays(name, ctx, monkeypatch):
     """EXTEND's box tests are FP32, quantised and conservative; the pair walk uses plain FP32 boxes and the oracle FP64
@@ -152,9 +238,10 @@ def test_extend_adversarial_rays(name, ctx, monkeypatch):
         assert np.all(np.abs(got["normal"][near] - ho["normal"][near]) < 1e-7), tag   # unfused FP64 differ at 1e-5 in p / r
 
 
+@pytest.mark.parametrize("count", [False, True], ids=["timed", "counting"])
 @pytest.mark.parametrize("name,region", [("cfg1", None), ("mix0", None), ("mix1", None), ("mix2", None),
                                          ("cfg2", (512, 256, 64, 32)), ("cfg5", (200, 380, 32, 16))])
-def test_radiance_matches_oracle(name, region, ctx):
+def test_radiance_matches_oracle(name, region, count, ctx):
     """GPU vs the CPU oracle on more pixels than the committed fixtures cover (oracle-sized regions)."""
     from oracle import zr_oracle_py as zo
     from raytracer_project_amd import capi
@@ -163,11 +250,24 @@ def test_radiance_matches_oracle(name, region, ctx):
     if name in ("cfg2", "cfg5"):
         cam.samples_per_pixel = 64  # keeps the CPU side in seconds; full-spp tiles are in the golden fixtures
     reg = capi.Region(*region, 0, 0, 0, 0) if region else None
-    gpu = gpu_scene(ctx, name).render(cam, ds.env, ds.seed, reg, count=True)
+    gpu = gpu_scene(ctx, name).render(cam, ds.env, ds.seed, reg, count=count)
     gctr = ctx.counters()
-    cpu, cctr, _, _ = zo.OracleScene(ds.desc).render(cam, ds.env, ds.seed, reg)
+    cpu, cctr, _, _ = _oracle_render(name, region, cam, ds, reg)
     _check(gpu, cpu, name)
-    assert (gctr.segments, gctr.rng_draws, gctr.hits) == (cctr.segments, cctr.rng_draws, cctr.hits)
+    if count:
+        assert (gctr.segments, gctr.rng_draws, gctr.hits) == (cctr.segments, cctr.rng_draws, cctr.hits)
+
+
+_oracle_cache = {}
+
+
+def _oracle_render(name, region, cam, ds, reg):
+    """the CPU side of test_radiance_matches_oracle, computed once per (scene, region)"""
+    from oracle import zr_oracle_py as zo
+    key = (name, region, cam.samples_per_pixel)
+    if key not in _oracle_cache:
+        _oracle_cache[key] = zo.OracleScene(ds.desc).render(cam, ds.env, ds.seed, reg)
+    return _oracle_cache[key]
 
 
 def test_empty_and_degenerate_scenes(ctx):
@@ -218,6 +318,27 @@ def test_tile_sharding_is_exact(ctx):
         acc += part
     assert np.array_equal(acc, full)
     assert np.isfinite(full).all() and (full >= 0).all() and 0.1 < full.mean() < 2.0
+
+
+def test_smallest_slot_pool_renders_the_same_image(built, monkeypatch):
+    """ZR_STREAM_SLOTS below 64 SHADE blocks used to leave the work units of unserved shards unrendered; the pool is now clamped
+    to 64 x 256 slots, and the image does not depend on the pool size (every sample is written once, reduced in a fixed order)."""
+    from raytracer_project_amd import capi
+    ds = demo_scene("mix0")
+    cam = ds.camera.copy()
+    cam.samples_per_pixel = 64
+    frames = []
+    for slots in ("4096", "1048576"):
+        monkeypatch.setenv("ZR_STREAM_SLOTS", slots)
+        c = capi.Context(0)
+        try:
+            sc = capi.Scene(c, ds.desc)
+            frames.append(sc.render(cam, ds.env, ds.seed, None, count=True))
+            assert c.counters().primary_samples == cam.image_width * cam.image_height * 64
+            sc.close()
+        finally:
+            c.close()
+    assert np.array_equal(frames[0], frames[1])
 
 
 def test_dropin_cpp_api_renders(ctx):
