@@ -242,13 +242,19 @@ uint32_t zr_scene_traversal_stack(const zr_scene*);
  * camera::render_accumulator) for the pixels of `region`; other pixels are left untouched.
  * `keep_going` (may be NULL) is polled between kernel batches and has render_flag's polarity
  * (camera.hpp:441): *keep_going == 0 stops the render (ZR_E_CANCELLED, finished batches are written).
- * `rows_done` (may be NULL) is advanced like camera::lines_rendered and set to H at the end. */
+ * `rows_done` (may be NULL) is advanced like camera::lines_rendered (camera.hpp:548-552): while the frame renders it holds
+ * H x the finished fraction of the frame's samples (the pipeline finishes samples all over the frame, not row by row) and
+ * it is set to H at the end (camera.hpp:576-578).  When rows_done is given, out_rgb is also refreshed a few times per
+ * second (ZR_PREVIEW_PERIOD_S, default 0.2) with the mean of the samples finished so far — the live preview the
+ * reference's GUI reads from render_accumulator mid-render (main.cpp:1576); the final image does not depend on it. */
 int zr_render(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed,
               const zr_region* region, int collect_counters,
               double* out_rgb, volatile const uint8_t* keep_going, volatile int* rows_done);
-/* Same, but the accumulator stays in HBM: d_out_rgb is a device pointer to W*H*3 doubles and the work
- * is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without a host sync.  This is
- * what the multi-GPU host uses before the RCCL reduce. */
+/* Same, but the accumulator stays in HBM: d_out_rgb is a device pointer to W*H*3 doubles and the kernels run on
+ * `hip_stream` (a hipStream_t, NULL = default stream), ordered after work already enqueued there.  The call BLOCKS until
+ * the frame is complete: the streaming pipeline's round loop reads the active-path count back every few rounds, so the
+ * stream is synchronised internally and is idle on return (no D2H copy of the frame takes place).  This is what the
+ * multi-GPU host uses before the RCCL exchange. */
 int zr_render_device(zr_ctx*, const zr_scene*, const zr_camera*, const zr_env*, uint64_t seed,
                      const zr_region* region, int collect_counters,
                      void* d_out_rgb, void* hip_stream);

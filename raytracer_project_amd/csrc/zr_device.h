@@ -253,6 +253,23 @@ __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, c
     return bare_t(sc, kind, idx, r, tmin, tmax, t);
 }
 
+// material id a hit on leaf object (kind, idx) will carry: the primitive's own, or that of the outermost material_instance
+// of its wrapper chain (material_instance.hpp:19-21; object_rec applies the chain inside-out, so the outermost one wins)
+__device__ inline uint32_t object_material(const DScene& sc, uint32_t kind, uint32_t idx) {
+    uint32_t type = kind, index = idx, mat_override = 0xFFFFFFFEu;
+    if (kind == ZR_KIND_WRAPPED) {
+        const DWrapped w = sc.wrapped[idx];
+        type = w.type; index = w.index;
+        for (uint32_t k = 0; k < w.chain_count; k++)
+            if (sc.ops[w.chain_first + k].kind == ZR_OP_MATERIAL) { mat_override = sc.ops[w.chain_first + k].mat; break; }
+    }
+    if (mat_override != 0xFFFFFFFEu) return mat_override;
+    if (type == ZR_PRIM_SPHERE) { const uint32_t m = sc.sphere_mat[index]; return m == 0xFFFFFFFFu ? m : (m & 0x7FFFFFFFu); }
+    if (type == ZR_PRIM_TRIANGLE) return (uint32_t)__double_as_longlong(sc.tri_s[(size_t)index * 20 + 18]);
+    if (type == ZR_PRIM_CUBE) return sc.cube_mat[index];
+    return sc.media[index].mat;
+}
+
 // ---- primitives: full hit record of the winner ------------------------------------------------------
 // `full` = false: u, v, tangent, bitangent are only computed when the hit's material reads them (a texture that
 // depends on u/v, or a bump map: zr_material::pad_ set by the host).  They are pure functions of the hit, so

@@ -6,11 +6,13 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -627,7 +629,7 @@ zr_ctx* zr_create(int device_ordinal) {
         if (env_double("ZR_STREAM_OVERLAP", -1) == 0) c->st_pools = 1;
         if (c->d_ctl.alloc((ST_MAX_POOLS + 1) * zr::stream_ctl_words()) != ZR_OK ||
             hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc((void**)&c->h_active, ST_MAX_POOLS * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
+            hipHostMalloc((void**)&c->h_active, (ST_MAX_POOLS + 1) * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
     if (c->variant == 1) {
         c->wf_blocks = zr::wavefront_max_blocks();
@@ -989,7 +991,8 @@ struct HostTimer : zr::StreamTimer {
 // needs the active-slot count), so zr_render_device returns with the frame complete.
 // mode 0: the render; 1 / 2: beauty pass and replay pass of the reflection / refraction split (zr_stream.hip, stream_shade)
 int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr::DEnv& de, uint64_t seed, const Plan& plan, int count,
-                  double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, int mode = 0, double* d_out2 = nullptr) {
+                  double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, int mode = 0, double* d_out2 = nullptr,
+                  zr::StreamProgress* progress = nullptr) {
     // pixel list (cached per plan)
     std::vector<int32_t> key = {plan.W, plan.H, plan.ts, plan.x0, plan.y0, plan.x1, plan.y1, (int32_t)plan.tiles.size(),
                                 plan.tiles.empty() ? -1 : plan.tiles.front(), plan.tiles.empty() ? -1 : plan.tiles.back()};
@@ -1028,7 +1031,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS))) return rc;
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
-    if (keep_going) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame reduces what exists
+    if (keep_going || progress) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame / a preview reduces what exists
     if (mode != 0) {
         if (c->d_kend.n < units * 2) { if ((rc = c->d_kend.alloc(units * 2))) return rc; }
         if (c->d_cls.n < units) { if ((rc = c->d_cls.alloc(units))) return rc; }
@@ -1045,7 +1048,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->generic_leaves, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr);
+                                     keep_going, &rounds, s->generic_leaves, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));
@@ -1054,7 +1057,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
 }
 
 int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* env, uint64_t seed, const Plan& plan, int count,
-                   double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done) {
+                   double* d_out, hipStream_t stream, volatile const uint8_t* keep_going, volatile int* rows_done, zr::StreamProgress* progress = nullptr) {
     c->last_rounds = 0;
     zr::DCamera dc; make_camera(*cam, dc);
     zr::DEnv de; make_env(*env, de);
@@ -1075,7 +1078,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         if (xb > xa && yb > ya) stream_units += (uint64_t)(xb - xa) * (yb - ya) * (uint64_t)dc.spp;
     }
     if (c->variant == 2 && dc.max_depth <= 250 && s->quad_ok && stream_units <= 0xFFFFFFFFull && plan.W <= 65535 && plan.H <= 65535) {
-        int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going);
+        int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going, 0, nullptr, progress);
         if (rows_done && r2 == ZR_OK) *rows_done = plan.H;
         return r2;
     }
@@ -1175,18 +1178,37 @@ int zr_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* 
     if ((rc = c->d_out.alloc(npx * 3))) return rc;
     HIP_OK(hipMemsetAsync(c->d_out.p, 0, npx * 3 * sizeof(double), c->stream));
     if (rows_done) *rows_done = 0;
-    int rrc = enqueue_render(c, s, cam, env, seed, plan, collect_counters, c->d_out.p, c->stream, keep_going, rows_done);
+    std::vector<double> frame(npx * 3);
+    auto copy_out = [&]() -> int {   // the region's pixels of the device frame -> the caller's buffer
+        HIP_OK(hipMemcpy(frame.data(), c->d_out.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int32_t t : plan.tiles) {
+            int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
+            int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
+            for (int y = ya; y < yb; y++)
+                if (xb > xa) std::memcpy(out_rgb + ((size_t)y * plan.W + xa) * 3, frame.data() + ((size_t)y * plan.W + xa) * 3, (size_t)(xb - xa) * 3 * sizeof(double));
+        }
+        return ZR_OK;
+    };
+    // Progress as the reference's callers see it: lines_rendered advances while the frame renders (camera.hpp:548-552) and the
+    // GUI reads render_accumulator mid-render (main.cpp:1576).  The pipeline finishes samples all over the frame rather than
+    // row by row, so `rows_done` = H x the finished fraction of the samples (H only at the very end), and a few times per second
+    // out_rgb receives the mean of the samples finished so far (every pixel brightens towards its final value).
+    struct Preview : zr::StreamProgress {
+        volatile int* rows; int H; double last = 0; std::function<int()> copy; double period;
+        static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+        bool wants_frame() override { return now() - last >= period; }
+        void report(double f, bool reduced) override {
+            const int r = std::min(H - 1, std::max(0, (int)(f * H)));
+            if (r > *rows) *rows = r;
+            if (reduced) { (void)copy(); last = now(); }
+        }
+    } preview;
+    preview.rows = rows_done; preview.H = plan.H; preview.copy = copy_out; preview.period = env_double("ZR_PREVIEW_PERIOD_S", 0.2); preview.last = Preview::now();
+    int rrc = enqueue_render(c, s, cam, env, seed, plan, collect_counters, c->d_out.p, c->stream, keep_going, rows_done, rows_done ? &preview : nullptr);
     if (rrc != ZR_OK && rrc != ZR_E_CANCELLED) return rrc;
     std::string cancel_msg = g_err;
     HIP_OK(hipStreamSynchronize(c->stream));
-    std::vector<double> frame(npx * 3);
-    HIP_OK(hipMemcpy(frame.data(), c->d_out.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int32_t t : plan.tiles) {
-        int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
-        int xa = std::max(tx, plan.x0), xb = std::min(tx + plan.ts, plan.x1), ya = std::max(ty, plan.y0), yb = std::min(ty + plan.ts, plan.y1);
-        for (int y = ya; y < yb; y++)
-            if (xb > xa) std::memcpy(out_rgb + ((size_t)y * plan.W + xa) * 3, frame.data() + ((size_t)y * plan.W + xa) * 3, (size_t)(xb - xa) * 3 * sizeof(double));
-    }
+    if ((rc = copy_out())) return rc;
     if (rrc == ZR_E_CANCELLED) { g_err = cancel_msg; return rrc; }
     if (rows_done) *rows_done = plan.H;  // camera.hpp:576-578
     return ZR_OK;

@@ -35,6 +35,14 @@ struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 exten
     virtual void end(hipStream_t, int kind) = 0;
     virtual ~StreamTimer() = default;
 };
+// host-provided progress sink of the round loop (camera::lines_rendered and the live preview of camera.hpp:548-552 / main.cpp:1576):
+// after every host synchronisation of the loop, report() gets the fraction of the frame's samples that are finished;
+// when wants_frame() said yes just before, `out` holds the mean of the samples finished so far (partial sums / spp)
+struct StreamProgress {
+    virtual bool wants_frame() = 0;
+    virtual void report(double finished_fraction, bool frame_reduced) = 0;
+    virtual ~StreamProgress() = default;
+};
 #define ST_MAX_POOLS 8   /* sub-pools of the slot pool, one HIP stream each */
 uint32_t stream_overflow_levels(uint32_t stack_demand);
 size_t stream_overflow_bytes(int blocks, uint32_t levels);
@@ -45,7 +53,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode = 0, void* d_kend = nullptr,
-                         void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr);
+                         void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr, StreamProgress* progress = nullptr);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
                         void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, bool generic,
                         hipStream_t stream);

@@ -421,30 +421,52 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     // the split passes count through LDS into a per-block record (a global atomic per thread costs ~1.5 ms per round and word)
     __shared__ unsigned long long s_cnt[4];
     if (MODE != 0 && threadIdx.x < 4) s_cnt[threadIdx.x] = 0;   // ordered before its use by the partition's barriers
-    // In-block partition: the 256 slots of this block are re-dealt to its threads so that slots whose ray HIT come
-    // first and misses / inactive slots last.  The hit path (hit record + scatter with its rejection sampler) and the
-    // miss path (background) are both long; unsorted, almost every wave runs both under half-empty exec masks.
+    // In-block MATERIAL SORT: the 256 slots of this block are re-dealt to its threads by what their segment will execute —
+    // class 0..4 = the hit's material kind (lambertian, metal, dielectric, light, isotropic: material.hpp:58-279,
+    // constant_medium.hpp:14-18), 5 = a hit without a valid material, 6 = miss (background), 7 = inactive slot — so that a
+    // wave runs one scatter routine (and one rejection sampler) under a full exec mask instead of five under sparse ones;
+    // unsorted, almost every wave of a mixed scene runs every branch.  A counting sort through LDS: per-wave ballots per class,
+    // a 4 x 8 table of counts, ranks by prefix popcount.  The material lookup it needs (primitive -> material id -> kind) is
+    // the first access of the lines the hit record reads anyway.
     __shared__ unsigned char perm[256];
-    __shared__ unsigned int wave_hits[4];
+    __shared__ unsigned int wave_cls[4][8];
     uint32_t slot;
 #ifdef ZR_SHADE_NO_PARTITION
     slot = slot0;
 #else
     {
-        bool is_hit = false;
+        uint32_t cls = 7;
         if (slot0 < B.P) {
             const uint2 m0 = B.ld2(SF_MA, slot0);
-            if (m0.y & F_ACTIVE) is_hit = B.ld2(SF_HIT_KI, slot0).x != 0xFFFFFFFFu;
+            if (m0.y & F_ACTIVE) {
+                const uint2 k0 = B.ld2(SF_HIT_KI, slot0);
+                if (k0.x == 0xFFFFFFFFu) cls = 6;
+                else {
+#ifdef ZR_SHADE_HITMISS_ONLY
+                    cls = 0;
+#else
+                    const uint32_t mat = object_material(sc, k0.x, k0.y);
+                    cls = mat < sc.n_mats ? sc.mats[mat].kind : 5u;
+                    if (cls > 5u) cls = 5u;
+#endif
+                }
+            }
         }
         const int w = threadIdx.x >> 6, wl = threadIdx.x & 63;
-        const unsigned long long hm = __ballot(is_hit);
-        if (wl == 0) wave_hits[w] = (unsigned int)__popcll(hm);
+        const unsigned long long below = (1ull << wl) - 1ull;
+        unsigned int my_rank = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {
+            const unsigned long long bm = __ballot(cls == c);
+            if (wl == 0) wave_cls[w][c] = (unsigned int)__popcll(bm);
+            if (cls == c) my_rank = (unsigned int)__popcll(bm & below);
+        }
         __syncthreads();
-        unsigned int hits_before = 0, hits_total = 0;
-        for (int k = 0; k < 4; k++) { if (k < w) hits_before += wave_hits[k]; hits_total += wave_hits[k]; }
-        const unsigned int rank_hit = hits_before + (unsigned int)__popcll(hm & ((1ull << wl) - 1ull));
-        const unsigned int rank_miss = (unsigned int)(w * 64 + wl) - rank_hit;   // non-hits before this thread
-        perm[is_hit ? rank_hit : hits_total + rank_miss] = (unsigned char)threadIdx.x;
+        unsigned int base = 0;   // slots of lower classes in any wave + slots of this class in earlier waves
+        for (uint32_t c = 0; c < 8; c++)
+            for (int k = 0; k < 4; k++)
+                if (c < cls || (c == cls && k < w)) base += wave_cls[k][c];
+        perm[base + my_rank] = (unsigned char)threadIdx.x;
         __syncthreads();
         slot = blockIdx.x * 256 + perm[threadIdx.x];
     }
@@ -750,7 +772,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode, void* d_kend, void* d_cls,
-                         double* out2, unsigned long long* d_cpart) {
+                         double* out2, unsigned long long* d_cpart, StreamProgress* progress) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     int K = n_pools < 1 ? 1 : (n_pools > ST_MAX_POOLS ? ST_MAX_POOLS : n_pools);
@@ -807,7 +829,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         shade(Q[k - 1], streams[k - 1]);
     }
     int rounds = K > 1 ? 1 : 0;
-    int check_every = 8;
+    int check_every = progress ? 2 : 8;
     bool cancelled = false;
     for (;;) {
         for (int r = 0; r < check_every; r++) {
@@ -816,13 +838,29 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         }
         for (int k = 0; k < K && e == hipSuccess; k++)
             e = hipMemcpyAsync(h_active + (size_t)k * W, d_ctl + (size_t)k * W, W * sizeof(unsigned int), hipMemcpyDeviceToHost, streams[k]);
+        if (progress && e == hipSuccess)   // the work-unit counters: how many samples have been started
+            e = hipMemcpyAsync(h_active + (size_t)ST_MAX_POOLS * W, uctl, W * sizeof(unsigned int), hipMemcpyDeviceToHost, streams[0]);
         for (int k = K - 1; k >= 0 && e == hipSuccess; k--) e = hipStreamSynchronize(streams[k]);
         if (e != hipSuccess) break;
         unsigned long long active = 0;
         for (int k = 0; k < K; k++)
             for (int sh = 0; sh < ST_SHARDS; sh++) active += h_active[(size_t)k * W + 16 + 32 * sh + 16];
+        if (progress && active != 0) {
+            unsigned long long started = P;   // the first P units are dealt at initialisation, the rest through the sharded counters
+            for (int sh = 0; sh < ST_SHARDS; sh++) started += h_active[(size_t)ST_MAX_POOLS * W + 32 * sh];
+            if (started > n_units) started = n_units;
+            const double frac = started > active ? (double)(started - active) / (double)n_units : 0.0;
+            bool reduced = false;
+            if (mode == 0 && out && progress->wants_frame()) {   // samples[] is zero-initialised in this case (render_stream)
+                hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, Q[0], cam, out);
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
+                reduced = true;
+            }
+            progress->report(frac, reduced);
+        }
         if (active == 0) break;
         check_every = active > P / 2 ? 8 : (active > P / 16 ? 4 : 2);
+        if (progress && check_every > 2) check_every = 2;   // an interactive caller: report (and poll keep_going) every other round
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }

@@ -527,6 +527,44 @@ def test_cancellation_and_progress(ctx):
     assert np.array_equal(sc.render(cam, ds.env, ds.seed, None), plain)
 
 
+def test_progress_and_preview_during_render(ctx, monkeypatch):
+    """camera::lines_rendered advances WHILE the frame renders and the caller's accumulator shows the partial frame
+    (camera.hpp:548-552, main.cpp:1576): a second thread watches rows_done and out_rgb during a zr_render call."""
+    import ctypes as C
+    import threading
+    import time
+    monkeypatch.setenv("ZR_PREVIEW_PERIOD_S", "0.02")
+    ds = demo_scene("cfg2")
+    cam = ds.camera.copy()
+    cam.samples_per_pixel = 256
+    sc = gpu_scene(ctx, "cfg2")
+    h, w = cam.image_height, cam.image_width
+    plain = sc.render(cam, ds.env, ds.seed, None)
+    out = np.zeros((h, w, 3))
+    flag = C.c_uint8(1); rows = C.c_int(0)
+    seen, partial_sums = [], []
+    done = threading.Event()
+
+    def watch():
+        while not done.is_set():
+            seen.append(rows.value)
+            partial_sums.append(float(out[::16, ::16].sum()))
+            time.sleep(0.002)
+    t = threading.Thread(target=watch); t.start()
+    try:
+        rc = ctx.lib.zr_render(ctx._c, sc._s, C.byref(cam), C.byref(ds.env), C.c_uint64(ds.seed), None, 0, out.ctypes.data,
+                               C.cast(C.byref(flag), C.c_void_p), C.cast(C.byref(rows), C.c_void_p))
+    finally:
+        done.set(); t.join()
+    assert rc == 0 and rows.value == h
+    assert np.array_equal(out, plain), "the preview must not change the final image"
+    mid = [r for r in seen if 0 < r < h]
+    assert len(set(mid)) >= 3, f"rows_done did not advance during the render: {sorted(set(seen))[:10]}"
+    assert seen == sorted(seen), "rows_done went backwards"
+    final = float(plain[::16, ::16].sum())
+    assert any(0.02 * final < p < 0.98 * final for p in partial_sums), "no partial frame was seen in the caller's buffer"
+
+
 def test_cxx_host_collective_single_rank(ctx):
     """zr_comm_*: the RCCL reduce entry points a C++ host uses.  With one rank the reduce is the identity; this checks the
     lazy librccl.so binding, communicator creation on the context's device and an in-place ncclReduce of doubles."""
