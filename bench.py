@@ -9,10 +9,11 @@ BASELINE.json — the 1 000 000-triangle mesh + HDRI IBL at 1920x1080, 512 spp, 
 configuration the metric's roofline target ("1M-triangle BVH traversal at 1 GPU") and the multi-GPU config (cfg4,
 "same 1M-tri scene pixel-tiled") are quoted on; cfg2 (configs[1]) and cfg5 are selectable with --workload.
 With N > 1 the frame's 32x32 pixel tiles are interleaved over the ranks (scene replicated, weak in memory but the
-total work is fixed => "strong" scaling) and the double3 accumulator is sum-reduced to rank 0 over RCCL every step.
+total work is fixed => "strong" scaling) and every step ends with one RCCL all-gather of the ranks' packed tiles (1/N of the
+double3 accumulator each), which rank 0 scatters into the frame.
 
 The timed region starts with the scene (BVH, vertices, normals, HDRI) resident in HBM and contains: zeroing the
-accumulator, the render kernel(s), the RCCL reduce.  One JSON line is printed by rank 0.
+accumulator, the render kernel(s), the RCCL exchange.  One JSON line is printed by rank 0.
 """
 import argparse
 import glob
@@ -153,7 +154,7 @@ def main():
     def step(count=False):
         acc.zero_()
         sc.render_device(cam, ds.env, ds.seed, acc.data_ptr(), stream, region, count)
-        multi.reduce_frame(acc, world)
+        multi.exchange_frame(acc, world)
 
     def barrier():
         if world > 1:

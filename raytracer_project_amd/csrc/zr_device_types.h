@@ -70,7 +70,7 @@ struct DScene {
     const zr_texture* texs;
     const unsigned char* texels;
     uint32_t n_mats;
-    uint32_t pad_;
+    uint32_t mat_kinds;  // bit k set: a material of kind k exists (SHADE sorts by kind only when more than one does)
     NodeF root;          // variant 2: the root of the 4-wide tree
 };
 

@@ -844,6 +844,8 @@ int zr_scene_commit(zr_scene* s) {
     d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.ops = s->d_ops.p;
     d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
     d.n_mats = (uint32_t)s->materials.size();
+    d.mat_kinds = 0;
+    for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
     d.root = fl.root;
     s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
     s->stack_demand = fl.stack_demand();

@@ -41,8 +41,8 @@ namespace zr {
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
 #ifndef ST_BIAS_NODE
-#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF */
-#define ST_BIAS_LEAF 1
+#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF; favouring LEAF 2:1 is 3 % faster on cfg3 (a tested leaf shrinks tbest and culls the stack), 1:1 and 3:1 are slower */
+#define ST_BIAS_LEAF 2
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 // relative part lowers the entry distance and raises the exit distance by |t| 2^-20.  An axis whose 1/d or o/d
 // leaves the float range gets id = 0, c = NaN: its planes evaluate to NaN, which fminf/fmaxf ignore, i.e. the slab
 // is dropped (conservative).
+enum { X_IDLE = 0, X_NODE = 1, X_LEAF = 2 };
 #define X_LEAF_BIT ZR_REF_LEAF
 
 __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32_t& rb) {
@@ -135,13 +136,6 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
     ta = t0; tb = t1; ra = r0; rb = r1;
 }
 
-// Lane state.  A lane works on up to TWO things at once: a current inner node (`hn`, `cur`) and one POSTPONED leaf (`hl`,
-// `lf`, `pend_i`).  A lane that reaches a leaf does not wait for the next LEAF phase: it parks the leaf and goes on walking
-// the next-nearest subtree, so it keeps taking part in NODE phases, and by the time a LEAF phase runs most lanes hold a
-// leaf (Aila & Laine's postponed leaf test).  With one state per lane the NODE phases of cfg3 ran with 30 of 64 lanes
-// and the LEAF phases with 26; the price is a few node visits that an earlier leaf hit would have culled.  A lane that
-// meets a second leaf while one is parked leaves it on the stack and waits for a LEAF phase ("blocked": !hn, hl, the top
-// of its stack is a leaf).  Idle = !hn && !hl, which implies an empty stack.
 // GENERIC = false: the world holds only bare triangles and spheres (no cubes, media or wrapped objects), so the
 // code for those leaf kinds — and the registers it needs — is compiled out (cfg2, cfg3).
 // Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
@@ -158,7 +152,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     const float INFf = __builtin_huge_valf();
     const uint32_t NONE = 0xFFFFFFFFu;
 
-    bool hn = false, hl = false;
+    int st = X_IDLE;
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     float idx_ = 0, idy_ = 0, idz_ = 0;
@@ -166,9 +160,8 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     double tbest = INF;
     float tbest_f = INFf;
     uint32_t kbest = NONE, ibest = 0;
-    uint32_t cur = 0;       // hn: quad index
-    uint32_t lf = 0;        // hl: leaf reference (kind << 28 | (count - 1) << 24 | first)
-    uint32_t pend_i = 0;    // hl: primitives of lf already tested
+    uint32_t cur = 0;       // X_NODE: quad index; X_LEAF: leaf reference (kind << 28 | (count - 1) << 24 | first)
+    uint32_t pend_i = 0;
     int sp = 0;
     Rng g; g.key = 0; g.k = 0; g.bounce = 0;  // only the medium test reads it
     bool work_left = true;
@@ -183,6 +176,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         uint2 ki; ki.x = kbest; ki.y = ibest;
         B.st2(SF_HIT_KI, slot, ki);
         if (COUNT && kbest != NONE) c_hits++;
+        st = X_IDLE;
     };
 // stack helpers are macros, not lambdas: a lambda capturing the __shared__ array by reference turns its accesses into
 // flat-pointer accesses (and trips an LLVM verifier error on gfx950)
@@ -193,18 +187,14 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         if (sp < ZR_LDS_LEVELS) lstack[sp * 64 + lane] = e_; else gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64] = e_; \
         sp++;                                                                                                   \
     }
-// the lane has no current node: take work off its stack, nearest first.  Entries beyond the current hit are dropped
-// without a fetch; an inner node becomes the current node; a leaf is parked if the leaf slot is free (and the search
-// goes on), else it stays on the stack and the lane waits for a LEAF phase.  Nothing left at all: the ray is done.
-#define ZR_ADVANCE()                                                                                            \
+// nearest deferred entry that can still matter, else the ray is done
+#define ZR_POP_NEXT()                                                                                           \
     for (;;) {                                                                                                  \
-        if (sp == 0) { if (!hl) finish(); break; }                                                              \
+        if (sp == 0) { finish(); break; }                                                                       \
+        sp--;                                                                                                   \
         SEntry e_;                                                                                              \
-        if (sp <= ZR_LDS_LEVELS) e_ = lstack[(sp - 1) * 64 + lane]; else e_ = gstack[(size_t)(sp - 1 - ZR_LDS_LEVELS) * 64]; \
-        if (!(e_.tn <= tbest_f)) { sp--; continue; }                                                            \
-        if (!(e_.node & X_LEAF_BIT)) { sp--; cur = e_.node; hn = true; break; }                                 \
-        if (hl) break;                                                                                          \
-        sp--; lf = e_.node; pend_i = 0; hl = true;                                                              \
+        if (sp < ZR_LDS_LEVELS) e_ = lstack[sp * 64 + lane]; else e_ = gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64]; \
+        if (e_.tn <= tbest_f) { cur = e_.node; pend_i = 0; st = (e_.node & X_LEAF_BIT) ? X_LEAF : X_NODE; break; } \
     }
 
 // one child from the parametric distances of its six planes (absolute slack already inside): entry distance or +inf
@@ -224,20 +214,15 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #define ZR_FBOX(N, C, TN, RF)                                                                               \
     ZR_SLAB(fmaf((N).lox[C], idx_, clx), fmaf((N).hix[C], idx_, chx), fmaf((N).loy[C], idy_, cly), fmaf((N).hiy[C], idy_, chy), \
             fmaf((N).loz[C], idz_, clz), fmaf((N).hiz[C], idz_, chz), (N).ref[C], TN, RF)
-// the four children by entry distance (5-comparator network): push far -> near, continue with the nearest.  A nearest
-// child that is a leaf is parked (and the lane goes on with the next entry) or, if a leaf is parked already, pushed too.
+// the four children by entry distance (5-comparator network): push far -> near, continue with the nearest
 #define ZR_DESCEND()                                                                                        \
     {                                                                                                       \
         cswap(tn0, r0, tn1, r1); cswap(tn2, r2, tn3, r3); cswap(tn0, r0, tn2, r2); cswap(tn1, r1, tn3, r3); cswap(tn1, r1, tn2, r2); \
-        hn = false;                                                                                         \
         if (tn3 < INFf) ZR_PUSH(r3, tn3)                                                                    \
         if (tn2 < INFf) ZR_PUSH(r2, tn2)                                                                    \
         if (tn1 < INFf) ZR_PUSH(r1, tn1)                                                                    \
-        if (tn0 < INFf) {                                                                                   \
-            if (!(r0 & X_LEAF_BIT)) { cur = r0; hn = true; }                                                \
-            else if (!hl) { lf = r0; pend_i = 0; hl = true; ZR_ADVANCE() }                                  \
-            else ZR_PUSH(r0, tn0)                                                                           \
-        } else { ZR_ADVANCE() }                                                                             \
+        if (tn0 < INFf) { cur = r0; pend_i = 0; st = (r0 & X_LEAF_BIT) ? X_LEAF : X_NODE; }                 \
+        else { ZR_POP_NEXT() }                                                                              \
     }
 
     const unsigned long long iter_cap = (unsigned long long)B.P * 64ull + (1ull << 24);
@@ -247,19 +232,19 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
     unsigned long long p_exec[3] = {0, 0, 0}, p_lanes[3] = {0, 0, 0};
 #endif
     for (; iter < iter_cap; iter++) {
-        const uint32_t lkind = (lf >> 28) & 7u;
-        const int n1 = __popcll(__ballot(hn));
-        const int n2t = __popcll(__ballot(hl && lkind == ZR_PRIM_TRIANGLE));
-        const int n2s = __popcll(__ballot(hl && lkind == ZR_PRIM_SPHERE));
-        const int n2g = GENERIC ? __popcll(__ballot(hl)) - n2t - n2s : 0;
-        const int n0 = work_left ? __popcll(__ballot(!hn && !hl)) : 0;
+        const uint32_t lkind = (cur >> 28) & 7u;
+        const int n1 = __popcll(__ballot(st == X_NODE));
+        const int n2t = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_TRIANGLE));
+        const int n2s = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_SPHERE));
+        const int n2g = GENERIC ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
+        const int n0 = work_left ? __popcll(__ballot(st == X_IDLE)) : 0;
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
         if (n1 + n2 + n0 == 0) break;
 
         if (n0 >= ST_FETCH_MIN || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
             // ================= FETCH: idle lanes take the next ray indices =================
             // rays are handed out from a wave-private chunk; one global atomic per ST_CHUNK rays
-            const unsigned long long idle = __ballot(!hn && !hl);
+            const unsigned long long idle = __ballot(st == X_IDLE);
             uint32_t n = (uint32_t)__popcll(idle);
 #ifdef ZR_WAVE_PROFILE
             p_exec[2]++; p_lanes[2] += n;
@@ -283,7 +268,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             const uint32_t base = chunk_next;
             chunk_next += n;
             const uint32_t lim = base + n;
-            if (!hn && !hl) {
+            if (st == X_IDLE) {
                 const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
                 if (my < lim) {
                     const uint2 m = B.ld2(SF_MA, my);
@@ -323,7 +308,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #ifdef ZR_WAVE_PROFILE
             p_exec[0]++; p_lanes[0] += n1;
 #endif
-            if (hn) {
+            if (st == X_NODE) {
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
                 const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
@@ -351,25 +336,26 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
 #ifdef ZR_WAVE_PROFILE
             p_exec[1]++; p_lanes[1] += n2;
 #endif
+            const bool is_leaf = st == X_LEAF;
             const bool do_tri = n2t == n2;
             const bool do_sph = !do_tri && n2s == n2;
-            const uint32_t prim = (lf & 0xFFFFFFu) + pend_i;
+            const uint32_t prim = (cur & 0xFFFFFFu) + pend_i;
             bool tested = false;
             if (do_tri) {
-                if (hl && lkind == ZR_PRIM_TRIANGLE) {
+                if (is_leaf && lkind == ZR_PRIM_TRIANGLE) {
                     double t;
                     if (COUNT) c_tri++;
                     if (triangle_t(sc.tri_v + (size_t)prim * 9, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
             } else if (do_sph) {
-                if (hl && lkind == ZR_PRIM_SPHERE) {
+                if (is_leaf && lkind == ZR_PRIM_SPHERE) {
                     double t;
                     if (COUNT) c_sph++;
                     if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
-            } else if (GENERIC && hl && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+            } else if (GENERIC && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
                 if (COUNT) {
                     uint32_t kk = lkind;
@@ -381,10 +367,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
             }
             if (tested) {
                 pend_i++;
-                if (pend_i > ((lf >> 24) & 0xFu)) {
-                    hl = false;
-                    if (!hn) { ZR_ADVANCE() }
-                }
+                if (pend_i > ((cur >> 24) & 0xFu)) { ZR_POP_NEXT() }
             }
         }
     }
@@ -427,7 +410,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     // wave runs one scatter routine (and one rejection sampler) under a full exec mask instead of five under sparse ones;
     // unsorted, almost every wave of a mixed scene runs every branch.  A counting sort through LDS: per-wave ballots per class,
     // a 4 x 8 table of counts, ranks by prefix popcount.  The material lookup it needs (primitive -> material id -> kind) is
-    // the first access of the lines the hit record reads anyway.
+    // the first access of the lines the hit record reads anyway; a scene with a single material kind skips it (hit / miss only).
     __shared__ unsigned char perm[256];
     __shared__ unsigned int wave_cls[4][8];
     uint32_t slot;
@@ -442,12 +425,13 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 const uint2 k0 = B.ld2(SF_HIT_KI, slot0);
                 if (k0.x == 0xFFFFFFFFu) cls = 6;
                 else {
-#ifdef ZR_SHADE_HITMISS_ONLY
                     cls = 0;
-#else
-                    const uint32_t mat = object_material(sc, k0.x, k0.y);
-                    cls = mat < sc.n_mats ? sc.mats[mat].kind : 5u;
-                    if (cls > 5u) cls = 5u;
+#ifndef ZR_SHADE_HITMISS_ONLY
+                    if (sc.mat_kinds & (sc.mat_kinds - 1u)) {   // more than one material kind in the scene (wave-uniform)
+                        const uint32_t mat = object_material(sc, k0.x, k0.y);
+                        cls = mat < sc.n_mats ? sc.mats[mat].kind : 5u;
+                        if (cls > 5u) cls = 5u;
+                    }
 #endif
                 }
             }

@@ -1,11 +1,16 @@
 """Pixel-tile sharding of one frame across the GPUs of a node: one process per GPU, scene replicated,
-interleaved 32x32 tiles (tile t -> rank t % world), and ONE collective per frame — a sum-reduce of the
-zero-initialised double3 accumulator to rank 0 (torch.distributed backend "nccl" = RCCL over xGMI).
+interleaved 32x32 tiles (tile t -> rank t % world), and ONE collective per frame (torch.distributed backend
+"nccl" = RCCL over xGMI): every rank packs the pixels of ITS tiles (1/world of the frame) and one all-gather hands
+the packed tiles round; rank 0 scatters them into the frame.  Each rank therefore sends 1/world of the double3 frame
+over each of its xGMI links (6.2 MB at 1080p and 8 ranks) instead of pushing the whole 49.8 MB frame — 7/8 of it
+zeros — through a ring sum-reduce (`exchange="reduce"`, the round-1 form, is kept for comparison).
 
 The reference shards rows across std::threads with no communication (camera.hpp:557-573); pixels are
-independent given the counter RNG (include/zr_rng.h), so there is no data-path collective other than the final
-gather.  Tiles are disjoint, so every pixel is the sum of one value and world-1 zeros: the reduce is exact and
-the multi-GPU image is bit-identical to the single-GPU one (tests/test_multi_gloo.py, tests/test_gpu_parity.py).
+independent given the counter RNG (include/zr_rng.h), so there is no data-path collective other than this final
+exchange, and it moves values without arithmetic: the multi-GPU image is bit-identical to the single-GPU one
+(tests/test_multi_gloo.py, tests/test_gpu_parity.py).  north_star speaks of a "reduce of the float3 accumulator"; the
+accumulator here is the reference's double3 render_accumulator (camera.hpp:420) and stays double — a float3 view would
+halve 6 MB of traffic that is already negligible and cost the bit-exactness.
 
 `render_tiles` is injected so that the same driver is exercised on CPU with gloo (tests) and on GPUs with RCCL
 (bench.py); this module contains no rendering arithmetic."""
@@ -57,6 +62,56 @@ def reduce_frame(acc, world, dst=0):
     return acc
 
 
+_owned = {}
+
+
+def owned_pixels(height, width, world, device, tile=TILE):
+    """per rank: flat pixel indices (y * width + x, ascending) of the tiles it owns; cached"""
+    import torch
+    key = (height, width, world, str(device), tile)
+    if key not in _owned:
+        ys = torch.arange(height, device=device).view(-1, 1)
+        xs = torch.arange(width, device=device).view(1, -1)
+        tiles_x = (width + tile - 1) // tile
+        owner = (torch.div(ys, tile, rounding_mode="floor") * tiles_x + torch.div(xs, tile, rounding_mode="floor")) % world
+        _owned[key] = [torch.nonzero(owner.reshape(-1) == r).reshape(-1) for r in range(world)]
+    return _owned[key]
+
+
+def gather_frame(acc, world, dst=0, tile=TILE):
+    """The one collective of a frame: all-gather of every rank's packed tiles (1/world of the frame each, padded to the
+    largest share), scattered into `acc` on rank `dst`.  Pure data movement: bit-exact."""
+    if world <= 1:
+        return acc
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    staged = dist.get_backend() == "gloo" and acc.is_cuda   # rehearsals on a box without one GPU per rank
+    frame = acc.cpu() if staged else acc
+    H, W = frame.shape[0], frame.shape[1]
+    own = owned_pixels(H, W, world, frame.device, tile)
+    m = max(int(o.numel()) for o in own)
+    flat = frame.view(-1, 3)
+    packed = torch.zeros((m, 3), dtype=frame.dtype, device=frame.device)
+    packed[:own[rank].numel()] = flat[own[rank]]
+    everyone = torch.empty((world * m, 3), dtype=frame.dtype, device=frame.device)
+    dist.all_gather_into_tensor(everyone, packed)
+    if rank == dst:
+        for r in range(world):
+            if r != rank:
+                flat[own[r]] = everyone[r * m:r * m + own[r].numel()]
+        if staged:
+            acc.copy_(frame)
+    return acc
+
+
+def exchange_frame(acc, world, dst=0, tile=TILE):
+    """packed-tile all-gather by default; ZR_MULTI_EXCHANGE=reduce selects the whole-frame sum-reduce"""
+    if os.environ.get("ZR_MULTI_EXCHANGE", "gather") == "reduce":
+        return reduce_frame(acc, world, dst)
+    return gather_frame(acc, world, dst, tile)
+
+
 def all_reduce_values(values, world, device, op="sum"):
     """all-reduce a short list of Python floats (bookkeeping: segment counts, elapsed time)."""
     import torch
@@ -69,9 +124,9 @@ def all_reduce_values(values, world, device, op="sum"):
     return t.tolist()
 
 
-def render_frame(render_tiles, acc, rank, world):
+def render_frame(render_tiles, acc, rank, world, tile=TILE):
     """acc: zero-initialised (H, W, 3) float64 tensor on this rank's device.  render_tiles(region_rank, region_world)
     must write this rank's pixels into acc (stream-ordered before the collective).  After the call rank 0 holds the
     whole frame."""
     render_tiles(rank, world)
-    return reduce_frame(acc, world)
+    return exchange_frame(acc, world, 0, tile)

@@ -145,7 +145,7 @@ def test_known_answers_on_hand_placed_inputs(engine, ctx, monkeypatch):
     h = ref_hit & keep
     tol = 1e-12
 
-    def close(a, b, what):
+    def close(a, b, what, tol=tol):
         err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
         assert err.max() <= tol, f"{what}: max error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
     close(hits["t"][h], recs[h, 1], "t"); close(hits["p"][h], recs[h, 2:5], "p"); close(hits["normal"][h], recs[h, 5:8], "normal")
@@ -167,7 +167,8 @@ def test_known_answers_on_hand_placed_inputs(engine, ctx, monkeypatch):
         bin_ = fx["bg_in"]
         for env_row in {tuple(r[:16]) for r in bin_}:
             sel = np.all(bin_[:, :16] == np.array(env_row), axis=1)
-            close(sc.kat_background(kat_env(env_row, ds.env.hdr_texture), bin_[sel, 16:19]), fx["bg_rgb"][sel], f"environment {env_row[:5]}")
+            # the edge of the sun disc is a smoothstep over 2e-4 of cos(angle): last-bit differences (FMA) are amplified 5000 x there
+            close(sc.kat_background(kat_env(env_row, ds.env.hdr_texture), bin_[sel, 16:19]), fx["bg_rgb"][sel], f"environment {env_row[:5]}", 1e-10)
         for scene in ("kat0", "cfg1"):
             d2 = demo_scene(scene)
             got = ctx.kat_camera_rays(d2.camera, d2.seed, fx[f"cam_req_{scene}"])
