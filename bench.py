@@ -133,7 +133,13 @@ def main():
 
     scene_name, scene_args, descr = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    ds = capi.DemoScene(scene_name, *scene_args)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)      # the drop-in's `model` announces itself on std::cout like the reference's (model.hpp:103):
+    os.dup2(2, 1)                 # keep this process's stdout to the one JSON line
+    try:
+        ds = capi.DemoScene(scene_name, *scene_args)
+    finally:
+        os.dup2(saved_stdout, 1); os.close(saved_stdout)
     t_scene = time.perf_counter() - t0
     cam = ds.camera.copy()
     if args.spp > 0:

@@ -1,0 +1,4 @@
+// color_processing.hpp — forwarding header of the MI355X drop-in: code written against the reference (#include "color_processing.hpp", /root/reference/color_processing.hpp)
+// compiles against include/zenith/zenith.hpp when this directory is on the include path instead of the reference's sources.
+#pragma once
+#include "../zenith.hpp"

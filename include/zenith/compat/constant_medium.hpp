@@ -1,0 +1,4 @@
+// constant_medium.hpp — forwarding header of the MI355X drop-in: code written against the reference (#include "constant_medium.hpp", /root/reference/constant_medium.hpp)
+// compiles against include/zenith/zenith.hpp when this directory is on the include path instead of the reference's sources.
+#pragma once
+#include "../zenith.hpp"

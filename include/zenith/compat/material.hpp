@@ -1,0 +1,4 @@
+// material.hpp — forwarding header of the MI355X drop-in: code written against the reference (#include "material.hpp", /root/reference/material.hpp)
+// compiles against include/zenith/zenith.hpp when this directory is on the include path instead of the reference's sources.
+#pragma once
+#include "../zenith.hpp"

@@ -1,0 +1,4 @@
+// rotate_y.hpp — forwarding header of the MI355X drop-in: code written against the reference (#include "rotate_y.hpp", /root/reference/rotate_y.hpp)
+// compiles against include/zenith/zenith.hpp when this directory is on the include path instead of the reference's sources.
+#pragma once
+#include "../zenith.hpp"

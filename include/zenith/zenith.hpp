@@ -37,6 +37,9 @@
 
 #include "../zr_capi.h"
 #include "../zr_rng.h"
+#ifdef ZENITH_STB_IMAGE
+#include "stb_image.h"
+#endif
 
 using std::make_shared;
 using std::shared_ptr;
@@ -351,10 +354,18 @@ private:
 // drop-in has its own readers for the two formats its scenes and tests use: Radiance .hdr (RGBE, flat or
 // new-style RLE scanlines) for is_hdr, binary PPM (P6, maxval 255) otherwise.  Anything else behaves
 // like the reference's failed load: width = height = 0 and value() returns cyan (texture.hpp:52-54).
+// A host that has stb_image on its include path (the reference vendors it under libs/stb) defines ZENITH_STB_IMAGE before
+// including this header (and STB_IMAGE_IMPLEMENTATION in one translation unit, as the reference's stb_impl.cpp does): every format
+// stb decodes (JPEG, PNG, ...) then loads exactly as in the reference — stbi_loadf / stbi_load with 3 channels forced
+// (texture.hpp:23,31) — and the built-in readers serve as the fallback.
 class image_texture : public texture {
 public:
     image_texture(const char* filename, bool is_hdr = false) : hdr(is_hdr) {
-        bool ok = is_hdr ? load_hdr(filename) : load_ppm(filename);
+        bool ok = false;
+#ifdef ZENITH_STB_IMAGE
+        ok = load_stb(filename);
+#endif
+        if (!ok) ok = is_hdr ? load_hdr(filename) : load_ppm(filename);
         if (!ok) {
             std::cerr << (is_hdr ? "ERROR: Could not load HDR: " : "ERROR: Could not load texture: ") << filename << "\n";
             width = height = 0; f32.clear(); u8.clear();
@@ -381,6 +392,21 @@ private:
     bool hdr; int width = 0, height = 0;
     std::vector<float> f32; std::vector<unsigned char> u8;
 
+#ifdef ZENITH_STB_IMAGE
+    bool load_stb(const char* fn) {   // texture.hpp:20-36
+        int w = 0, h = 0, ch = 0;
+        if (hdr) {
+            float* d = stbi_loadf(fn, &w, &h, &ch, 3);
+            if (!d) return false;
+            f32.assign(d, d + (size_t)w * h * 3); stbi_image_free(d);
+        } else {
+            unsigned char* d = stbi_load(fn, &w, &h, &ch, 3);
+            if (!d) return false;
+            u8.assign(d, d + (size_t)w * h * 3); stbi_image_free(d);
+        }
+        width = w; height = h; return w > 0 && h > 0;
+    }
+#endif
     bool load_ppm(const char* fn) {
         std::ifstream f(fn, std::ios::binary);
         if (!f) return false;

@@ -323,8 +323,11 @@ int zr_get_kernel_times(zr_ctx*, float* ms, int cap);
 
 /* ---- multi-GPU: the one collective of a frame, for hosts that stay C++ (no torch) ---------------------------- */
 /* One process per GPU.  Each rank renders its interleaved tiles with zr_render_device(region.tile_mod = nranks,
- * region.tile_rem = rank) into a zero-initialised W*H*3 double frame in HBM; zr_comm_reduce_frame then sums the frames
- * onto `root` in place (ncclReduce, ncclDouble, ncclSum over RCCL / xGMI).  Tiles are disjoint, so the sum is exact.
+ * region.tile_rem = rank, region.tile_size) into a W*H*3 double frame in HBM.  zr_comm_gather_frame then packs the pixels of
+ * the rank's own tiles (1/nranks of the frame), hands the packed tiles round with ONE ncclAllGather and scatters the other
+ * ranks' tiles into `root`'s frame: each rank sends its share once over each xGMI link instead of pushing a whole frame of
+ * mostly zeros through a ring reduce, and no arithmetic touches the pixels.  zr_comm_reduce_frame is the round-1 form: the
+ * zero-initialised frames summed onto `root` in place (ncclReduce, ncclDouble, ncclSum); tiles are disjoint, so it is exact too.
  * The reference has no counterpart: it shards rows over std::threads in one address space (camera.hpp:557-573).
  * librccl.so is loaded lazily (dlopen) by these entry points only. */
 #define ZR_COMM_ID_BYTES 128
@@ -332,6 +335,7 @@ typedef struct zr_comm zr_comm;
 int zr_comm_unique_id(unsigned char id[ZR_COMM_ID_BYTES]);  /* rank 0 creates it and ships it to the other ranks */
 zr_comm* zr_comm_create(zr_ctx*, int nranks, int rank, const unsigned char id[ZR_COMM_ID_BYTES]);
 int zr_comm_reduce_frame(zr_comm*, void* d_frame, size_t n_doubles, int root, void* hip_stream);
+int zr_comm_gather_frame(zr_comm*, void* d_frame, int W, int H, int tile_size /* 0 = 32 */, int root, void* hip_stream);
 void zr_comm_destroy(zr_comm*);
 
 /* ---- known-answer entry: world.hit(r, interval(tmin,tmax), rec) for a batch of rays ---------- */

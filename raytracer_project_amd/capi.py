@@ -157,7 +157,7 @@ CAPI_SYMBOLS = [
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
     "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
-    "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_destroy",
+    "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_gather_frame", "zr_comm_destroy",
 ]
 
 
@@ -206,6 +206,7 @@ def load():
     lib.zr_comm_unique_id.argtypes = [vp]
     lib.zr_comm_create.restype = vp; lib.zr_comm_create.argtypes = [vp, i32, i32, vp]
     lib.zr_comm_reduce_frame.argtypes = [vp, vp, C.c_size_t, i32, vp]
+    lib.zr_comm_gather_frame.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     lib.zr_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib

@@ -29,6 +29,8 @@ struct Builder {
     const std::vector<BuildBox>& boxes;
     const std::vector<uint32_t>& kinds;
     int max_leaf, depth_limit;
+    int leaf_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per kind; 0 = max_leaf
+    int cap_of(uint32_t kind) const { const int c = leaf_cap[kind & 7]; return c > 0 && c < max_leaf ? c : max_leaf; }
     double ct;
     const double* ck;
     std::vector<BuildNode> nodes;
@@ -109,7 +111,7 @@ struct Builder {
                 double leaf_cost = 0;
                 for (uint32_t i = 0; i < count; i++) leaf_cost += ck[kinds[order[first + i]] & 7];
                 leaf_cost *= pa; (void)leaf_cost_each;
-                if ((int)count <= max_leaf && homo && leaf_cost <= split_cost) { make_leaf(); return; }
+                if (homo && (int)count <= cap_of(kinds[order[first]]) && leaf_cost <= split_cost) { make_leaf(); return; }
                 double lo = cb.lo[best_axis], scale = kBins / (cb.hi[best_axis] - cb.lo[best_axis]);
                 auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t o) {
                     const BuildBox& b = boxes[o];
@@ -119,10 +121,10 @@ struct Builder {
                 });
                 mid = (uint32_t)(it - order.begin());
                 have_split = mid > first && mid < first + count;
-            } else if ((int)count <= max_leaf && homo) {
+            } else if (homo && (int)count <= cap_of(kinds[order[first]])) {
                 make_leaf(); return;  // all centroids coincide
             }
-        } else if ((int)count <= max_leaf && homo) {
+        } else if (homo && (int)count <= cap_of(kinds[order[first]])) {
             make_leaf(); return;
         }
         if (!have_split) {
@@ -156,13 +158,14 @@ struct Builder {
 }  // namespace
 
 void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& kinds, int max_leaf, int depth_limit,
-               double cost_traverse, const double cost_kind[8], BuildResult& out) {
+               double cost_traverse, const double cost_kind[8], BuildResult& out, const int* max_leaf_kind) {
     out.nodes.clear(); out.order.clear(); out.max_depth = 0;
     const uint32_t n = (uint32_t)boxes.size();
     if (n == 0) return;
     Builder b(boxes, kinds);
     b.max_leaf = std::max(1, std::min(max_leaf, 0xFFFF));
     b.depth_limit = depth_limit; b.ct = cost_traverse; b.ck = cost_kind;
+    if (max_leaf_kind) for (int k = 0; k < 8; k++) b.leaf_cap[k] = max_leaf_kind[k];
     b.nodes.resize((size_t)2 * n);
     b.order.resize(n);
     for (uint32_t i = 0; i < n; i++) b.order[i] = i;

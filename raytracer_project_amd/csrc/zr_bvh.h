@@ -25,7 +25,9 @@ struct BuildResult {
 
 // boxes/kinds: one per object.  Leaves hold <= max_leaf objects of one kind.  depth_limit bounds the
 // depth of any leaf (the traversal stack is sized from it).
+// max_leaf_kind[k] (may be null) caps the leaves of kind k below max_leaf: expensive objects with large boxes (cubes, media,
+// wrapped objects) get leaves of their own.
 void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& kinds, int max_leaf, int depth_limit,
-               double cost_traverse, const double cost_kind[8], BuildResult& out);
+               double cost_traverse, const double cost_kind[8], BuildResult& out, const int* max_leaf_kind = nullptr);
 
 }  // namespace zr

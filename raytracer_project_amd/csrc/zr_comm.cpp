@@ -1,12 +1,17 @@
-// zr_comm.cpp — the frame's one collective for C++ hosts: ncclReduce of the double3 accumulator over RCCL / xGMI.
+// zr_comm.cpp — the frame's one collective for C++ hosts, over RCCL / xGMI: every rank packs the pixels of the tiles it owns
+// (1/nranks of the double3 frame), one ncclAllGather hands the packed tiles round and the root scatters them into its frame
+// (zr_comm_gather_frame); the whole-frame ncclReduce of round 1 stays available (zr_comm_reduce_frame).
 // librccl.so is resolved lazily with dlopen so that libzr_hip.so itself has no RCCL dependency (single-GPU hosts and
-// the Python host, which reduces through torch.distributed, never load it).
+// the Python host, which exchanges through torch.distributed, never load it).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/zr_capi.h"
 
@@ -20,6 +25,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -32,9 +38,10 @@ bool load_rccl() {
     g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, void*))dlsym(g_rccl.lib, "ncclReduce");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, void*))dlsym(g_rccl.lib, "ncclAllGather");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
-    return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.Reduce && g_rccl.CommDestroy;
+    return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.Reduce && g_rccl.AllGather && g_rccl.CommDestroy;
 }
 int nccl_fail(const char* what, int rc) {
     std::string m = std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
@@ -42,7 +49,21 @@ int nccl_fail(const char* what, int rc) {
 }
 }  // namespace
 
-struct zr_comm { void* comm = nullptr; int device = 0; int nranks = 1, rank = 0; };
+// device side of the exchange (zr_post.hip): frame pixels <-> a rank's packed tile list
+namespace zr {
+hipError_t launch_pack_tiles(const double* frame, const uint32_t* idx, size_t n, double* packed, hipStream_t stream);
+hipError_t launch_unpack_tiles(double* frame, const uint32_t* idx, size_t n, const double* packed, hipStream_t stream);
+}
+
+struct zr_comm {
+    void* comm = nullptr; int device = 0; int nranks = 1, rank = 0;
+    // packed-tile exchange: per rank the flat pixel indices (y * W + x, ascending) of the tiles it owns, cached per frame geometry
+    int W = 0, H = 0, tile = 0;
+    std::vector<size_t> first, count;     // rank r owns idx[first[r] .. first[r] + count[r])
+    size_t share = 0;                     // max over ranks of count[r]: the all-gather's fixed element count
+    uint32_t* d_idx = nullptr; double* d_packed = nullptr; double* d_all = nullptr;
+    void release() { if (d_idx) (void)hipFree(d_idx); if (d_packed) (void)hipFree(d_packed); if (d_all) (void)hipFree(d_all); d_idx = nullptr; d_packed = d_all = nullptr; }
+};
 
 extern "C" {
 
@@ -74,8 +95,55 @@ int zr_comm_reduce_frame(zr_comm* c, void* d_frame, size_t n_doubles, int root, 
     return rc == 0 ? ZR_OK : nccl_fail("ncclReduce", rc);
 }
 
+int zr_comm_gather_frame(zr_comm* c, void* d_frame, int W, int H, int tile_size, int root, void* hip_stream) {
+    if (!c || !d_frame) return zr_internal_fail(ZR_E_INVALID, "null argument");
+    if (W < 1 || H < 1 || (size_t)W * H > 0xFFFFFFFFull) return zr_internal_fail(ZR_E_INVALID, "bad frame size");
+    if (root < 0 || root >= c->nranks) return zr_internal_fail(ZR_E_INVALID, "root out of range");
+    if (hipSetDevice(c->device) != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, "hipSetDevice failed");
+    const int ts = tile_size > 0 ? tile_size : 32;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (W != c->W || H != c->H || ts != c->tile) {   // (re)build the ownership lists: tile t = (y / ts) * tiles_x + x / ts belongs to rank t % nranks
+        c->release();
+        const int tiles_x = (W + ts - 1) / ts;
+        std::vector<std::vector<uint32_t>> own((size_t)c->nranks);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) own[(size_t)(((y / ts) * tiles_x + x / ts) % c->nranks)].push_back((uint32_t)((size_t)y * W + x));
+        c->first.assign((size_t)c->nranks, 0); c->count.assign((size_t)c->nranks, 0); c->share = 0;
+        std::vector<uint32_t> flat; flat.reserve((size_t)W * H);
+        for (int r = 0; r < c->nranks; r++) {
+            c->first[r] = flat.size(); c->count[r] = own[r].size();
+            flat.insert(flat.end(), own[r].begin(), own[r].end());
+            if (own[r].size() > c->share) c->share = own[r].size();
+        }
+        if (hipMalloc((void**)&c->d_idx, std::max<size_t>(flat.size(), 1) * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&c->d_packed, std::max<size_t>(c->share, 1) * 3 * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&c->d_all, std::max<size_t>(c->share, 1) * 3 * sizeof(double) * (size_t)c->nranks) != hipSuccess ||
+            hipMemcpy(c->d_idx, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            c->release(); c->W = c->H = c->tile = 0;
+            return zr_internal_fail(ZR_E_DEVICE, "zr_comm_gather_frame: out of device memory");
+        }
+        if (hipMemset(c->d_packed, 0, std::max<size_t>(c->share, 1) * 3 * sizeof(double)) != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, "hipMemset failed");
+        c->W = W; c->H = H; c->tile = ts;
+    }
+    if (c->share == 0) return ZR_OK;
+    hipError_t e = zr::launch_pack_tiles((const double*)d_frame, c->d_idx + c->first[c->rank], c->count[c->rank], c->d_packed, st);
+    if (e != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, hipGetErrorString(e));
+    const int ncclDouble = 8;
+    int rc = g_rccl.AllGather(c->d_packed, c->d_all, c->share * 3, ncclDouble, c->comm, hip_stream);
+    if (rc != 0) return nccl_fail("ncclAllGather", rc);
+    if (c->rank == root)
+        for (int r = 0; r < c->nranks; r++) {
+            if (r == c->rank || c->count[r] == 0) continue;
+            e = zr::launch_unpack_tiles((double*)d_frame, c->d_idx + c->first[r], c->count[r], c->d_all + (size_t)r * c->share * 3, st);
+            if (e != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, hipGetErrorString(e));
+        }
+    return ZR_OK;
+}
+
 void zr_comm_destroy(zr_comm* c) {
     if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->release();
     if (c->comm && g_rccl.CommDestroy) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); }
     delete c;
 }

@@ -213,6 +213,23 @@ __device__ __forceinline__ bool cube_t(const double* q, const Ray& r, double tmi
     return true;
 }
 
+// A placed cube: the ray goes through translate::hit's and rotate_y::hit's first halves (translate.hpp:15-22, rotate_y.hpp:44-56)
+// exactly as chain_ray would apply them, then cube::hit — the wrapper parameters come with the record instead of from an op list
+__device__ __forceinline__ Ray pcube_ray(const double* q, Ray r) {
+    r.o = r.o - mk(q[6], q[7], q[8]);
+    if (q[11] != 0.0) {
+        const double s = q[9], c = q[10];
+        const double ox = c * r.o.x + s * r.o.z, oz = -s * r.o.x + c * r.o.z;
+        const double dx = c * r.d.x + s * r.d.z, dz = -s * r.d.x + c * r.d.z;
+        r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+    }
+    return r;
+}
+__device__ __forceinline__ bool pcube_t(const double* q, const Ray& r, double tmin, double tmax, double& t) {
+    const Ray lr = pcube_ray(q, r);
+    return cube_t(q, lr, tmin, tmax, t);
+}
+
 __device__ inline bool bare_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, double& t) {
     if (kind == ZR_PRIM_SPHERE) return sphere_t(sc.spheres + (size_t)idx * 4, r, tmin, tmax, t);
     if (kind == ZR_PRIM_CUBE) return cube_t(sc.cubes + (size_t)idx * 6, r, tmin, tmax, t);
@@ -240,6 +257,34 @@ __device__ inline bool medium_t(const DScene& sc, uint32_t idx, const Ray& r, do
     return true;
 }
 
+// a medium whose boundary is an unwrapped sphere or cube (DMedium::chain_count == 0): medium_t without the op-list loop and the
+// triangle branch — the same arithmetic, since an empty chain leaves the ray as it is
+__device__ inline bool medium_plain_t(const DScene& sc, uint32_t idx, const Ray& r, double tmin, double tmax, const Rng& g, double& t) {
+    const DMedium& m = sc.media[idx];
+    double t1, t2;
+    const double inf = __builtin_huge_val();
+    if (m.btype == ZR_PRIM_SPHERE) {
+        const double* q = sc.spheres + (size_t)m.bindex * 4;
+        if (!sphere_t(q, r, -inf, inf, t1)) return false;
+        if (!sphere_t(q, r, t1 + 0.0001, inf, t2)) return false;
+    } else {
+        const double* q = sc.cubes + (size_t)m.bindex * 6;
+        if (!cube_t(q, r, -inf, inf, t1)) return false;
+        if (!cube_t(q, r, t1 + 0.0001, inf, t2)) return false;
+    }
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    double rl = len(r.d);
+    double inside = (t2 - t1) * rl;
+    double xi = zr_bits_to_unit(zr_medium_bits(g.key, g.bounce, m.id));
+    double hd = m.neg_inv_density * log(xi);
+    if (hd > inside) return false;
+    t = t1 + hd / rl;
+    return true;
+}
+
 // any leaf object
 __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, const Rng& g,
                                 double& t) {
@@ -249,6 +294,7 @@ __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, c
         if (w.type == ZR_PRIM_MEDIUM) return medium_t(sc, w.index, lr, tmin, tmax, g, t);
         return bare_t(sc, w.type, w.index, lr, tmin, tmax, t);
     }
+    if (kind == ZR_KIND_PCUBE) return pcube_t(sc.pcubes + (size_t)idx * 12, r, tmin, tmax, t);
     if (kind == ZR_PRIM_MEDIUM) return medium_t(sc, idx, r, tmin, tmax, g, t);
     return bare_t(sc, kind, idx, r, tmin, tmax, t);
 }
@@ -264,6 +310,7 @@ __device__ inline uint32_t object_material(const DScene& sc, uint32_t kind, uint
             if (sc.ops[w.chain_first + k].kind == ZR_OP_MATERIAL) { mat_override = sc.ops[w.chain_first + k].mat; break; }
     }
     if (mat_override != 0xFFFFFFFEu) return mat_override;
+    if (type == ZR_KIND_PCUBE) return sc.pcube_mat[index];
     if (type == ZR_PRIM_SPHERE) { const uint32_t m = sc.sphere_mat[index]; return m == 0xFFFFFFFFu ? m : (m & 0x7FFFFFFFu); }
     if (type == ZR_PRIM_TRIANGLE) return (uint32_t)__double_as_longlong(sc.tri_s[(size_t)index * 20 + 18]);
     if (type == ZR_PRIM_CUBE) return sc.cube_mat[index];
@@ -319,8 +366,7 @@ __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r
     rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
 }
 
-__device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) {  // cube.hpp:73-142
-    const double* q = sc.cubes + (size_t)idx * 6;
+__device__ inline void cube_rec_q(const double* q, uint32_t mat, const Ray& r, double t, Rec& rec) {  // cube.hpp:73-142
     V3 he = ld3(q), center = ld3(q + 3);
     rec.t = t;
     rec.p = at(r, t);
@@ -340,9 +386,10 @@ __device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, do
         rec.n = mk(0, 0, 1); rec.u = (p.x + he.x) / (2 * he.x); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(1, 0, 0);
     }
     rec.bit = cross(rec.n, rec.tan);
-    rec.mat = sc.cube_mat[idx];
+    rec.mat = mat;
     set_face(rec, r.d, rec.n);
 }
+__device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) { cube_rec_q(sc.cubes + (size_t)idx * 6, sc.cube_mat[idx], r, t, rec); }
 
 __device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full) {
     if (kind == ZR_PRIM_SPHERE) sphere_rec(sc, idx, r, t, rec, full);
@@ -361,6 +408,16 @@ __device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, c
 // hit record of leaf object (kind, idx) hit by world ray r at distance t
 // `full`: compute every field (known-answer entry); otherwise u/v/tangent only when the material reads them
 __device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full = false) {
+    if (kind == ZR_KIND_PCUBE) {   // cube::hit's record in object space, then the second halves of rotate_y::hit and translate::hit, inside-out
+        const double* q = sc.pcubes + (size_t)idx * 12;
+        const Ray lr = pcube_ray(q, r);
+        cube_rec_q(q, sc.pcube_mat[idx], lr, t, rec);
+        zr_xform_op op; op.mat = 0;
+        if (q[11] != 0.0) { op.kind = ZR_OP_ROTATE_Y; op.a[0] = q[9]; op.a[1] = q[10]; op.a[2] = 0; apply_op_rec(op, r.d, rec); }   // the ray rotate_y received: translated only, same direction
+        op.kind = ZR_OP_TRANSLATE; op.a[0] = q[6]; op.a[1] = q[7]; op.a[2] = q[8];
+        apply_op_rec(op, r.d, rec);
+        return;
+    }
     if (kind != ZR_KIND_WRAPPED) { bare_rec(sc, kind, idx, r, t, rec, full); return; }
     const DWrapped w = sc.wrapped[idx];
     Ray lr = chain_ray(sc, w.chain_first, w.chain_count, r);
@@ -436,7 +493,7 @@ __device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, 
                     if (COUNT) {
                         uint32_t kk = kind;
                         if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[c[s] + k].type;
-                        if (kk == ZR_PRIM_SPHERE) ctr.sph++; else if (kk == ZR_PRIM_TRIANGLE) ctr.tri++; else if (kk == ZR_PRIM_CUBE) ctr.cube++; else ctr.med++;
+                        if (kk == ZR_PRIM_SPHERE) ctr.sph++; else if (kk == ZR_PRIM_TRIANGLE) ctr.tri++; else if (kk == ZR_PRIM_CUBE || kk == ZR_KIND_PCUBE) ctr.cube++; else ctr.med++;
                     }
                     if (object_t(sc, kind, c[s] + k, r, tmin, tbest, g, t)) { tbest = t; kbest = kind; ibest = c[s] + k; }
                 }

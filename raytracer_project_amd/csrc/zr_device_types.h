@@ -4,6 +4,8 @@
 #include "../../include/zr_capi.h"
 
 #define ZR_KIND_WRAPPED 4u /* leaf kind: object with a wrapper chain (index into DScene::wrapped) */
+#define ZR_KIND_PCUBE 5u   /* leaf kind: a "placed" cube — cube -> [rotate_y] -> translate, the way every cube of the reference's scenes enters the
+                              world (scene_management.hpp:132-139): the two wrapper parameters travel with the cube (DScene::pcubes) */
 #define ZR_STACK_DEPTH 48  /* builder guarantees tree depth <= ZR_STACK_DEPTH */
 #define ZR_MAX_CHAIN 8
 
@@ -63,6 +65,8 @@ struct DScene {
                                 // [19] low word bit 0 = front_face forced true (triangle baked from under a translate / rotate_y)
     const double* cubes;        // 6 per cube: half extents, centre
     const uint32_t* cube_mat;
+    const double* pcubes;       // placed cubes, 12 per cube: half extents, centre | translate offset | rotate_y sin, cos, has_rotation | (pad)
+    const uint32_t* pcube_mat;
     const DMedium* media;
     const DWrapped* wrapped;
     const zr_xform_op* ops;

@@ -136,8 +136,8 @@ struct zr_scene {
     DevBuf<zr::NodePair> d_nodes;
     DevBuf<zr::NodeQ> d_quads;
     bool quad_ok = true;          // leaf references fit the EXTEND kernel's 32-bit stack entries
-    DevBuf<double> d_spheres, d_tri_v, d_tri_s, d_cubes;
-    DevBuf<uint32_t> d_sphere_mat, d_cube_mat;
+    DevBuf<double> d_spheres, d_tri_v, d_tri_s, d_cubes, d_pcubes;
+    DevBuf<uint32_t> d_sphere_mat, d_cube_mat, d_pcube_mat;
     DevBuf<zr::DMedium> d_media;
     DevBuf<zr::DWrapped> d_wrapped;
     DevBuf<zr_xform_op> d_ops;
@@ -145,7 +145,7 @@ struct zr_scene {
     DevBuf<zr_texture> d_texs;
     DevBuf<unsigned char> d_texels;
     zr::DScene ds{};
-    bool generic_leaves = true;   // the BVH has leaves other than bare triangles / spheres
+    int leaf_level = 2;           // EXTEND build: 0 bare triangles / spheres only, 1 + bare and placed cubes and unwrapped media, 2 everything
     uint32_t stack_demand = 0;    // worst-case entries on an EXTEND lane's traversal stack (Flattener::stack_demand)
     uint64_t stats[4] = {0, 0, 0, 0};
 };
@@ -275,8 +275,8 @@ struct Flattener {
     std::vector<zr::NodeQ> quads;
     std::vector<uint32_t> leaf_first;  // per build node: device index of a leaf's first primitive
     int quad_depth = 0;
-    std::vector<double> spheres, tri_v, tri_s, cubes;
-    std::vector<uint32_t> sphere_mat, cube_mat;
+    std::vector<double> spheres, tri_v, tri_s, cubes, pcubes;
+    std::vector<uint32_t> sphere_mat, cube_mat, pcube_mat;
     std::vector<zr::DMedium> media;
     std::vector<zr::DWrapped> wrapped;
 
@@ -379,6 +379,26 @@ struct Flattener {
         n_baked++;
         return (uint32_t)sphere_mat.size() - 1;
     }
+    // A cube under translate, or under rotate_y then translate (material_instance wrappers anywhere) — how every cube of the
+    // reference's scenes is placed (scene_management.hpp:132-139, cfg5's walls and boxes) — is stored as a PLACED CUBE: the cube's
+    // own numbers plus the two wrappers' parameters in one record.  The device applies the wrappers' ray and hit-record maps in the
+    // chain's order with the chain's arithmetic (zr_device.h pcube_ray / object_rec), so results are those of the wrapped object;
+    // what is saved is the op-list loop, its loads and the registers of the generic chain code in the traversal kernel.
+    uint32_t append_pcube(const zr_object& o) {
+        const double* q = &s.cubes[(size_t)o.index * 12];
+        double rec[12] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0};
+        uint32_t mat = s.cube_mat[o.index];
+        for (int k = (int)o.chain_count - 1; k >= 0; k--) {   // inside-out: the outermost material_instance is applied last
+            const zr_xform_op& op = s.ops[o.chain_first + k];
+            if (op.kind == ZR_OP_TRANSLATE) { rec[6] = op.a[0]; rec[7] = op.a[1]; rec[8] = op.a[2]; }
+            else if (op.kind == ZR_OP_ROTATE_Y) { rec[9] = op.a[0]; rec[10] = op.a[1]; rec[11] = 1.0; }
+            else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+        }
+        pcubes.insert(pcubes.end(), rec, rec + 12);
+        pcube_mat.push_back(mat);
+        n_baked++;
+        return (uint32_t)pcube_mat.size() - 1;
+    }
     // returns the first device index of the leaf's objects within its kind's array
     uint32_t append_leaf(const zr::BuildNode& n) {
         uint32_t first = 0;
@@ -390,6 +410,8 @@ struct Flattener {
                 di = append_baked_triangle(o);
             } else if (baked && (*baked)[oi] == 3) {
                 di = append_baked_sphere(o);
+            } else if (baked && (*baked)[oi] == 4) {
+                di = append_pcube(o);
             } else if (baked && (*baked)[oi] == 2) {
                 di = append_prim(o.type, o.index, s.ops[o.chain_first].mat);   // the outermost wrapper is applied last
                 n_baked++;
@@ -781,6 +803,17 @@ int zr_scene_commit(zr_scene* s) {
             }
             if (ok && moved && mat < 0x7FFFFFFFu) { baked[k] = 3; kinds[k] = ZR_PRIM_SPHERE; }
         }
+        if (bake && o.type == ZR_PRIM_CUBE && o.chain_count > 0) {   // see Flattener::append_pcube: [translate] or [translate, rotate_y], outermost first
+            int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
+            for (uint32_t q = 0; q < o.chain_count && ok; q++) {
+                const uint32_t kd = s->ops[o.chain_first + q].kind;
+                if (kd == ZR_OP_MATERIAL) continue;
+                if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
+                else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
+                else ok = false;
+            }
+            if (ok && pat >= 1) { baked[k] = 4; kinds[k] = ZR_KIND_PCUBE; }
+        }
         if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
             bool only_material = true;
             for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
@@ -791,9 +824,12 @@ int zr_scene_commit(zr_scene* s) {
     }
     zr::BuildResult br;
     double ck[8] = {env_double("ZR_BVH_COST_SPHERE", 1.0), env_double("ZR_BVH_COST_TRI", 1.5), env_double("ZR_BVH_COST_CUBE", 1.0),
-                    env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), 1, 1, 1};
+                    env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), env_double("ZR_BVH_COST_PCUBE", 1.5), 1, 1};
     int max_leaf = (int)env_double("ZR_BVH_MAX_LEAF", 4);
-    zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br);
+    // cubes, media and wrapped objects are few, large and dear to test: one per leaf, so that a ray only tests those whose own box it enters
+    const int big = (int)env_double("ZR_BVH_MAX_LEAF_BIG", 1);
+    const int leaf_cap[8] = {0, 0, big, big, big, big, 0, 0};
+    zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br, leaf_cap);
     if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
 
     Flattener fl{*s, objs, br};
@@ -805,13 +841,15 @@ int zr_scene_commit(zr_scene* s) {
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
     s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
-                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24);
+                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24);
     if ((rc = s->d_spheres.upload(fl.spheres))) return rc;
     if ((rc = s->d_sphere_mat.upload(fl.sphere_mat))) return rc;
     if ((rc = s->d_tri_v.upload(fl.tri_v))) return rc;
     if ((rc = s->d_tri_s.upload(fl.tri_s))) return rc;
     if ((rc = s->d_cubes.upload(fl.cubes))) return rc;
     if ((rc = s->d_cube_mat.upload(fl.cube_mat))) return rc;
+    if ((rc = s->d_pcubes.upload(fl.pcubes))) return rc;
+    if ((rc = s->d_pcube_mat.upload(fl.pcube_mat))) return rc;
     if ((rc = s->d_media.upload(fl.media))) return rc;
     if ((rc = s->d_wrapped.upload(fl.wrapped))) return rc;
     if ((rc = s->d_ops.upload(s->ops))) return rc;
@@ -841,17 +879,26 @@ int zr_scene_commit(zr_scene* s) {
     d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
     d.tri_v = s->d_tri_v.p; d.tri_s = s->d_tri_s.p;
     d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
+    d.pcubes = s->d_pcubes.p; d.pcube_mat = s->d_pcube_mat.p;
     d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.ops = s->d_ops.p;
     d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
     d.n_mats = (uint32_t)s->materials.size();
     d.mat_kinds = 0;
     for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
     d.root = fl.root;
-    s->generic_leaves = !fl.cubes.empty() || !fl.media.empty() || !fl.wrapped.empty();
+    {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
+        bool plain_media = true;   // media whose boundary is an unwrapped sphere or cube
+        for (const zr::DMedium& m : fl.media) if (m.chain_count != 0) plain_media = false;
+        if (!fl.wrapped.empty() || !plain_media) s->leaf_level = 2;
+        else if (!fl.cubes.empty() || !fl.pcube_mat.empty() || !fl.media.empty()) s->leaf_level = 1;
+        else s->leaf_level = 0;
+        const int force = (int)env_double("ZR_EXTEND_LEVEL", -1);
+        if (force > s->leaf_level && force <= 2) s->leaf_level = force;
+    }
     s->stack_demand = fl.stack_demand();
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", fl.quad_depth, s->stack_demand);
     s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
-    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size()) * 8 +
+    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size() + fl.pcubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
     s->committed = true;
     return ZR_OK;
@@ -1050,7 +1097,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->generic_leaves, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress);
+                                     keep_going, &rounds, s->leaf_level, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));
@@ -1446,7 +1493,7 @@ int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double
         if ((rc = pool.alloc(zr::stream_pool_bytes((uint32_t)n) + 65536))) return rc;
         HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
         HIP_OK(zr::stream_trace(s->ds, d_rays.p, (uint32_t)n, seed, pixel, bounce, d_hits.p, pool.p, c->d_ctl.p, c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks,
-                                c->d_ctr.p, s->generic_leaves, c->stream));
+                                c->d_ctr.p, s->leaf_level, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
         unsigned int capped = 0;
         HIP_OK(hipMemcpy(&capped, c->d_ctl.p + 2, sizeof capped, hipMemcpyDeviceToHost));

@@ -256,4 +256,28 @@ hipError_t launch_analyze(const double* d_frame, size_t n, double* d_part_log, f
     return hipGetLastError();
 }
 
+// ---- multi-GPU exchange (zr_comm.cpp): frame pixels <-> a rank's packed tile list; pure data movement -----------------------
+__global__ __launch_bounds__(256) void pack_tiles(const double* __restrict__ frame, const uint32_t* __restrict__ idx, size_t n, double* __restrict__ packed) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const double* p = frame + (size_t)idx[k] * 3;
+    packed[k * 3] = p[0]; packed[k * 3 + 1] = p[1]; packed[k * 3 + 2] = p[2];
+}
+__global__ __launch_bounds__(256) void unpack_tiles(double* __restrict__ frame, const uint32_t* __restrict__ idx, size_t n, const double* __restrict__ packed) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double* p = frame + (size_t)idx[k] * 3;
+    p[0] = packed[k * 3]; p[1] = packed[k * 3 + 1]; p[2] = packed[k * 3 + 2];
+}
+hipError_t launch_pack_tiles(const double* frame, const uint32_t* idx, size_t n, double* packed, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, frame, idx, n, packed);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_tiles(double* frame, const uint32_t* idx, size_t n, const double* packed, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, frame, idx, n, packed);
+    return hipGetLastError();
+}
+
 }  // namespace zr

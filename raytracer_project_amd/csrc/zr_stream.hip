@@ -37,6 +37,9 @@ namespace zr {
 #ifndef ST_EXT_WAVES_LEAN
 #define ST_EXT_WAVES_LEAN 6  /* same for the triangles-and-spheres-only build of EXTEND */
 #endif
+#ifndef ST_EXT_WAVES_MID
+#define ST_EXT_WAVES_MID 5   /* ... and for the build that adds bare / placed cubes and unwrapped media (cfg5) */
+#endif
 #ifndef ST_FETCH_MIN
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
@@ -136,13 +139,16 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
     ta = t0; tb = t1; ra = r0; rb = r1;
 }
 
-// GENERIC = false: the world holds only bare triangles and spheres (no cubes, media or wrapped objects), so the
-// code for those leaf kinds — and the registers it needs — is compiled out (cfg2, cfg3).
+// LEVEL: which leaf kinds the build knows, chosen per scene at commit (zr_scene::leaf_level) so that a world pays only for
+// the code — and the registers — of what it contains:
+//   0  bare triangles and spheres (cfg2, cfg3)
+//   1  + bare cubes, placed cubes (cube -> [rotate_y] -> translate) and media in an unwrapped sphere or cube (cfg5)
+//   2  + objects under arbitrary wrapper chains and wrapped media (the op-list interpreter)
 // Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
 // host sizes the slab from the exact worst-case demand of the committed tree (Flattener::stack_demand), so no push can
 // leave it.
-template <bool COUNT, bool GENERIC>
-__global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
+template <bool COUNT, int LEVEL>
+__global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
                                                                   uint32_t ovf_levels, unsigned long long* __restrict__ gctr) {
     __shared__ SEntry lstack[ST_LDS_STACK * 64];
     const int lane = threadIdx.x;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
         const int n1 = __popcll(__ballot(st == X_NODE));
         const int n2t = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_TRIANGLE));
         const int n2s = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_SPHERE));
-        const int n2g = GENERIC ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
+        const int n2g = LEVEL > 0 ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
         const int n0 = work_left ? __popcll(__ballot(st == X_IDLE)) : 0;
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
         if (n1 + n2 + n0 == 0) break;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
                     if (m.y & F_ACTIVE) {
                         slot = my;
                         ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
-                        if (GENERIC) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
+                        if (LEVEL > 0) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
                         {
                             const float NANf = __builtin_nanf("");
                             idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
@@ -355,14 +361,20 @@ __global__ __launch_bounds__(64, GENERIC ? ST_EXT_WAVES : ST_EXT_WAVES_LEAN) voi
                     if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
-            } else if (GENERIC && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+            } else if (LEVEL > 0 && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
                 if (COUNT) {
                     uint32_t kk = lkind;
                     if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[prim].type;
-                    if (kk == ZR_PRIM_SPHERE) c_sph++; else if (kk == ZR_PRIM_TRIANGLE) c_tri++; else if (kk == ZR_PRIM_CUBE) c_cube++; else c_med++;
+                    if (kk == ZR_PRIM_SPHERE) c_sph++; else if (kk == ZR_PRIM_TRIANGLE) c_tri++; else if (kk == ZR_PRIM_CUBE || kk == ZR_KIND_PCUBE) c_cube++; else c_med++;
                 }
-                if (object_t(sc, lkind, prim, ray, 0.001, tbest, g, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
+                bool h;
+                if (LEVEL == 1) {   // cubes, placed cubes, plain media: no op-list interpreter in this build
+                    if (lkind == ZR_KIND_PCUBE) h = pcube_t(sc.pcubes + (size_t)prim * 12, ray, 0.001, tbest, t);
+                    else if (lkind == ZR_PRIM_CUBE) h = cube_t(sc.cubes + (size_t)prim * 6, ray, 0.001, tbest, t);
+                    else h = medium_plain_t(sc, prim, ray, 0.001, tbest, g, t);
+                } else h = object_t(sc, lkind, prim, ray, 0.001, tbest, g, t);
+                if (h) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                 tested = true;
             }
             if (tested) {
@@ -726,8 +738,8 @@ int stream_extend_blocks() {
         if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     }
     int lean = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false, true>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lean, stream_extend<false, false>, 64, 0) == hipSuccess && lean > per_cu) per_cu = lean;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false, 2>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lean, stream_extend<false, 0>, 64, 0) == hipSuccess && lean > per_cu) per_cu = lean;
     return cus * per_cu;
 }
 
@@ -743,9 +755,10 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
 }
 
 template <bool COUNT>
-static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, uint32_t ovf_levels, int blocks, unsigned long long* gctr, bool generic, hipStream_t st) {
-    if (generic) hipLaunchKernelGGL((stream_extend<COUNT, true>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
-    else hipLaunchKernelGGL((stream_extend<COUNT, false>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, uint32_t ovf_levels, int blocks, unsigned long long* gctr, int level, hipStream_t st) {
+    if (level >= 2) hipLaunchKernelGGL((stream_extend<COUNT, 2>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else if (level == 1) hipLaunchKernelGGL((stream_extend<COUNT, 1>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else hipLaunchKernelGGL((stream_extend<COUNT, 0>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
 }
 
 // The slot pool can be split into K sub-pools that run a fraction of a round apart on K HIP streams, so that one
@@ -755,7 +768,7 @@ static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, 
 hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, void* pool, uint32_t P, uint32_t spp,
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
-                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, bool generic, int mode, void* d_kend, void* d_cls,
+                         unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int generic, int mode, void* d_kend, void* d_cls,
                          double* out2, unsigned long long* d_cpart, StreamProgress* progress) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
@@ -862,7 +875,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
 
 // closest hits of n rays in [0.001, inf) through the EXTEND kernel; `pool` holds stream_pool_bytes(round_up(n, 64)) bytes
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
-                        void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, bool generic,
+                        void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, int generic,
                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const uint32_t P = (n + 63u) / 64u * 64u;

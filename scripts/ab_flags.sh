@@ -3,7 +3,7 @@
 # tests and later steps of the same gpurun call load — is never replaced by an instrumented or experimental build.
 R=$GRAFT_REPO_ROOT
 S=${TMPDIR:-/tmp}/zr_ab_$$
-run() { python3 $R/bench.py --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python3 -c 'import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("ms_per_step", d["ms_per_step"], "extend ms/launch", r["kernel_ms"], "per step", r["kernel_ms_per_step"], "launches", r["launches_timed"], "checksum", d["config"]["frame_checksum"])'; }
+run() { python3 $R/bench.py --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python3 -c 'import json,sys; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); r=d["roofline"]; print("ms_per_step", d["ms_per_step"], "extend ms/launch", r["kernel_ms"], "per step", r["kernel_ms_per_step"], "launches", r["launches_timed"], "checksum", d["config"]["frame_checksum"])'; }
 echo "in-tree: $(run)"
 mkdir -p $S/raytracer_project_amd && cp -r $R/include $S/ && cp -r $R/scenes $S/ && cp -r $R/raytracer_project_amd/csrc $S/raytracer_project_amd/
 for f in "$@"; do
