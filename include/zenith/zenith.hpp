@@ -60,6 +60,14 @@ inline void seed_rng(uint64_t seed, uint64_t pixel = ZR_SCENE_PIXEL, uint64_t sa
 }
 }  // namespace zenith
 inline double random_double() { auto& s = zenith::rng_state(); return zr_bits_to_unit(zr_stream_bits(s.key, s.k++)); }
+namespace zenith {
+// The reference's bvh_node constructor draws random_int(0, 2) once per node it creates (bvh.hpp:17): one node per span of 1 or 2
+// objects, 1 + left + right for longer spans split at span / 2 (bvh.hpp:25-41).  The drop-in builds its own tree at commit, but
+// whoever constructs a bvh_node or loads a model (model.hpp:95) must find random_double() where the reference leaves it, or
+// every random scene decision made afterwards differs: the constructors below consume exactly that many draws.
+inline uint64_t bvh_ctor_draws(size_t n) { return n <= 2 ? (n ? 1 : 0) : 1 + bvh_ctor_draws(n / 2) + bvh_ctor_draws(n - n / 2); }
+inline void consume_draws(uint64_t n) { rng_state().k += n; }
+}  // namespace zenith
 inline double random_double(double lo, double hi) { return lo + (hi - lo) * random_double(); }
 inline int random_int(int lo, int hi) { return static_cast<int>(random_double(lo, hi + 1)); }
 
@@ -773,7 +781,7 @@ private:
 // ---- bvh.hpp: the tree itself is built on the device side of the ABI (zr_scene_commit) ---------------
 class bvh_node : public hittable {
 public:
-    bvh_node(hittable_list list) : list(std::move(list)) {}
+    bvh_node(hittable_list l) : list(std::move(l)) { zenith::consume_draws(zenith::bvh_ctor_draws(list.objects.size())); }
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return list.bounding_box(); }
     void flatten(zenith::scene_builder& b) const override { list.flatten(b); }
@@ -862,6 +870,7 @@ public:
                 for (size_t k = 1; k + 1 < fc.size(); k++) emit(fc[0], fc[k], fc[k + 1]);
             }
         }
+        zenith::consume_draws(zenith::bvh_ctor_draws(tris.size()));   // mesh_bvh = make_shared<bvh_node>(triangles), model.hpp:95
         std::cout << "Model: " << filename << " loaded (" << tris.size() << " triangles)." << std::endl;
     }
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }

@@ -71,6 +71,8 @@ static shared_ptr<hittable> zr_hook_medium(shared_ptr<hittable> m) { return make
 
 #include "../scenes/zr_scenes.inc"
 #include "../scenes/zr_scenes_mix.inc"
+#include "scene_management.hpp"             // the reference's own demo scene: load_materials / sceneAssetsLoader / build_geometry
+#include "../scenes/zr_scene_refdemo.inc"
 
 // counts closest-hit queries ("segments") and publishes the bounce index for the medium key
 struct seg_tls_t { uint64_t segments = 0; };
@@ -211,6 +213,7 @@ struct built_scene {
 static bool build(built_scene& b, const std::string& name, int a0, int a1, int a2, int a3) {
     g_next_medium_id = 0;
     bool ok = zr_build_scene(name, b.s, a0, a1, a2, a3) || zr_build_scene_mix(name, b.s);
+    if (!ok && name == "refdemo") { zr_build_refdemo(b.s); ok = true; }   // needs the reference's assets/ tree in the working directory
     if (!ok) return false;
     // bvh_node's constructor draws random_int(0,2) per node (bvh.hpp:17): give it its own scene stream
     zr_oracle_seed(b.s.seed, ZR_SCENE_PIXEL, 1);
