@@ -773,8 +773,13 @@ int zr_scene_commit(zr_scene* s) {
         for (uint32_t k = 0; k < s->cube_mat.size(); k++) if (!cb[k]) objs.push_back({ZR_PRIM_CUBE, k, 0, 0});
         for (uint32_t k = 0; k < s->media.size(); k++) objs.push_back({ZR_PRIM_MEDIUM, k, 0, 0});
     }
+    const bool commit_stats = std::getenv("ZR_COMMIT_STATS") != nullptr;
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_phase = now_s();
+    auto phase = [&](const char* what) { if (commit_stats) { const double t = now_s(); std::fprintf(stderr, "[zr] commit: %-22s %.1f ms\n", what, (t - t_phase) * 1e3); t_phase = t; } };
     int rc = validate(*s, objs);
     if (rc) return rc;
+    phase("world list + validate");
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
 
     // boxes + kinds
@@ -829,13 +834,16 @@ int zr_scene_commit(zr_scene* s) {
     // cubes, media and wrapped objects are few, large and dear to test: one per leaf, so that a ray only tests those whose own box it enters
     const int big = (int)env_double("ZR_BVH_MAX_LEAF_BIG", 1);
     const int leaf_cap[8] = {0, 0, big, big, big, big, 0, 0};
+    phase("boxes");
     zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br, leaf_cap);
+    phase("binned-SAH build");
     if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
 
     Flattener fl{*s, objs, br};
     fl.baked = &baked;
     fl.open_ratio = env_double("ZR_BVH_OPEN_RATIO", 1.25);
     fl.run();
+    phase("flatten + quantise");
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
@@ -901,6 +909,7 @@ int zr_scene_commit(zr_scene* s) {
     s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size() + fl.pcubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
     s->committed = true;
+    phase("upload");
     return ZR_OK;
 }
 
