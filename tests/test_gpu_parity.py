@@ -304,6 +304,40 @@ def test_empty_and_degenerate_scenes(ctx):
     _check(out, cpu, "single sphere")
 
 
+def test_deep_tree_sizes_the_traversal_stack(ctx, monkeypatch):
+    """A world built to need a deep traversal stack: 600 concentric spherical shells, every one a leaf of its own, all of them
+    overlapping every ray through the centre.  The committed scene reports its exact worst-case stack demand
+    (zr_scene_traversal_stack), the per-wave spill slabs are sized from it, and EXTEND's answers equal the pair walk's and the
+    oracle's — no push can leave the slab (the round-1 kernel assumed 48 entries)."""
+    import ctypes as C
+    from oracle import zr_oracle_py as zo
+    from raytracer_project_amd import capi
+    n = 600
+    sph = np.zeros((n, 4)); sph[:, 3] = 1.0 * 1.01 ** np.arange(n)         # same centre, radii 1 ... 390
+    mats = np.zeros(n, dtype=np.uint32)
+    mat = (capi.Material * 1)(capi.Material(0, 0, capi.NO_TEXTURE, 0, 0.0, 1.0, (C.c_double * 3)(1, 1, 1)))
+    tex = (capi.Texture * 1)(capi.Texture(0, 0, 0, 0, 0, 0, 0, 1.0, (C.c_double * 3)(0.5, 0.5, 0.5)))
+    d = capi.SceneDesc()
+    d.spheres = sph.ctypes.data; d.sphere_mat = mats.ctypes.data; d.n_spheres = n
+    d.materials = C.cast(mat, C.c_void_p); d.n_materials = 1
+    d.textures = C.cast(tex, C.c_void_p); d.n_textures = 1
+    monkeypatch.setenv("ZR_BVH_MAX_LEAF", "1")
+    sc = capi.Scene(ctx, d)
+    demand = sc.stats()["traversal_stack"]
+    assert demand > 12, demand      # more than the LDS part of the stack: the HBM slab is in use
+    rng = np.random.default_rng(3)
+    o = rng.normal(size=(4000, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(0.0, 500.0, (4000, 1))
+    rays = np.concatenate([o, -o + rng.normal(scale=0.05, size=(4000, 3))], axis=1)   # towards the centre: through every shell
+    want = zo.OracleScene(d).trace(rays)
+    for engine in ("extend", "pairs"):
+        monkeypatch.setenv("ZR_TRACE_ENGINE", engine)
+        got = sc.trace(rays)
+        assert np.array_equal(got["mat"], want["mat"]), engine
+        h = want["mat"] != 0xFFFFFFFF
+        assert h.sum() > 3000 and np.all(rel_err(got["t"][h], want["t"][h], 1e-300) < 1e-9), engine
+    sc.close()
+
+
 def test_tile_sharding_is_exact(ctx):
     """Pixel tiles rendered by different 'ranks' (tile_mod / tile_rem) reassemble to the single-GPU image bit for bit,
     so the multi-GPU reduce (sum with zeros) is exact."""
