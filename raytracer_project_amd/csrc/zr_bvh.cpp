@@ -5,8 +5,9 @@
 //   * object references are 48-byte records {float box, float centroid, id, kind} that are PHYSICALLY partitioned, so every
 //     pass streams memory instead of gathering 48-byte double boxes through an index array;
 //   * one pass bins all three axes (16 bins each); the split is the best of the 45 candidate planes;
-//   * the top of the tree (nodes above kTeamNode references) is built one node at a time by the whole thread team — chunked
-//     binning with per-thread bins, a stable two-pass parallel partition — and the subtrees below are dealt to the threads;
+//   * the top of the tree is built by teams of threads: a team splits its node together (chunked binning with per-thread bins,
+//     a stable two-pass parallel partition), then divides itself between the two sides in proportion to their sizes and the
+//     subtrees proceed concurrently; a team of one — or a node below kTeamNode references — builds serially;
 //   * node boxes are exact: floats only rank split candidates; every node's box is the union of its objects' double boxes,
 //     taken on the way back up.
 // The tree is a pure function of the input (the parallel partition is stable, subtrees are independent), whatever the
@@ -29,7 +30,7 @@ namespace zr {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kTeamNode = 1u << 16;   // nodes with more references than this are built by the whole team
+constexpr uint32_t kTeamNode = 1u << 13;   // nodes with fewer references are not worth a team: the team's threads cost more than they save
 constexpr uint32_t kSweep = 16;            // nodes up to this size: exact sweep over the sorted references instead of bins
 const double kInf = std::numeric_limits<double>::infinity();
 const float kInfF = std::numeric_limits<float>::infinity();
@@ -104,9 +105,6 @@ struct Builder {
     NodeArray nodes;
     std::atomic<uint32_t> n_nodes{0};
     std::atomic<int> max_depth{0};
-
-    struct Task { uint32_t id, first, count; int depth; FBox cb; };
-    std::vector<Task> tasks;   // subtrees handed to single threads
 
     explicit Builder(const std::vector<BuildBox>& b) : boxes(b) {}
 
@@ -314,26 +312,26 @@ struct Builder {
         build(r, mid, first + count - mid, depth + 1, cbr);
         nodes[id].box = nodes[l].box; grow(nodes[id].box, nodes[r].box);
     }
-    // top of the tree: the team splits one node at a time, subtrees small enough become tasks
-    void build_top(uint32_t id, uint32_t first, uint32_t count, int depth, const FBox& cb) {
-        if (count <= kTeamNode || team <= 1) { tasks.push_back(Task{id, first, count, depth, cb}); return; }
+    // top of the tree: a team of threads splits the node (chunked binning, stable parallel partition), then the team itself
+    // splits — in proportion to the two sides — and the two subtrees proceed concurrently; a team of one builds serially.
+    void build_team(uint32_t id, uint32_t first, uint32_t count, int depth, const FBox& cb, int tm) {
+        if (tm <= 1 || count <= kTeamNode) { build(id, first, count, depth, cb); return; }
         FBox cbl, cbr;
-        const uint32_t mid = split_node(id, first, count, depth, team, cb, cbl, cbr);
+        // splitting together pays from ~16K references per thread; below that the node is split by one thread and only the two
+        // subtrees run concurrently
+        const int par = count >= 4 * kTeamNode ? std::min(tm, (int)(count / (2 * kTeamNode))) : 1;
+        const uint32_t mid = split_node(id, first, count, depth, par, cb, cbl, cbr);
         if (mid == first) return;
         const uint32_t l = alloc(), r = alloc();
         nodes[id].left = (int32_t)l; nodes[id].right = (int32_t)r; nodes[id].count = 0; nodes[id].first = 0; nodes[id].kind = 0;
-        build_top(l, first, mid - first, depth + 1, cbl);
-        build_top(r, mid, first + count - mid, depth + 1, cbr);
+        const uint32_t lc = mid - first, rc = first + count - mid;
+        int tl = (int)((uint64_t)tm * lc / count);
+        tl = tl < 1 ? 1 : (tl > tm - 1 ? tm - 1 : tl);
+        std::thread other([&, this]() { build_team(l, first, lc, depth + 1, cbl, tl); });
+        build_team(r, mid, rc, depth + 1, cbr, tm - tl);
+        other.join();
+        nodes[id].box = nodes[l].box; grow(nodes[id].box, nodes[r].box);
     }
-    void finish_top(uint32_t id) {   // boxes of the nodes above the tasks
-        BuildNode& n = nodes[id];
-        if (n.count || n.left < 0) return;
-        if (top_done[id]) return;
-        finish_top((uint32_t)n.left); finish_top((uint32_t)n.right);
-        n.box = nodes[n.left].box; grow(n.box, nodes[n.right].box);
-        top_done[id] = 1;
-    }
-    std::vector<char> top_done;
 };
 
 }  // namespace
@@ -350,8 +348,8 @@ void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& 
     if (max_leaf_kind) for (int k = 0; k < 8; k++) b.leaf_cap[k] = max_leaf_kind[k];
     unsigned hw = std::thread::hardware_concurrency();
     if (const char* e = std::getenv("ZR_BVH_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
-    b.team = (int)std::max(1u, std::min(32u, hw));
-    if (n < 4 * kTeamNode) b.team = std::min(b.team, n < kTeamNode ? 1 : 4);
+    b.team = (int)std::max(1u, std::min(64u, hw));
+    if (n < 64 * kTeamNode) b.team = std::max(1, std::min(b.team, (int)(n / kTeamNode)));
     // nothing below is value-initialised: pages are first touched by the threads that fill them
     b.nodes.allocate((size_t)2 * n);
     b.refs.allocate(n); b.tmp.allocate(b.team > 1 ? n : 0);
@@ -375,24 +373,9 @@ void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& 
     double t0 = now();
     const uint32_t root = b.alloc();
     b.nodes[root].left = b.nodes[root].right = -1; b.nodes[root].count = 0; b.nodes[root].first = 0; b.nodes[root].kind = 0;
-    b.build_top(root, 0, n, 0, cb);
-    double t1 = now();
-    // the subtrees: largest first, dealt through one counter
-    std::stable_sort(b.tasks.begin(), b.tasks.end(), [](const Builder::Task& x, const Builder::Task& y) { return x.count > y.count; });
-    std::atomic<size_t> next{0};
-    team_run(b.team, [&](int) {
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= b.tasks.size()) break;
-            const Builder::Task& t = b.tasks[k];
-            b.build(t.id, t.first, t.count, t.depth, t.cb);
-        }
-    });
-    double t2 = now();
+    b.build_team(root, 0, n, 0, cb, b.team);
+    double t1 = now(), t2 = t1;
     const uint32_t used = b.n_nodes.load();
-    b.top_done.assign(used, 0);
-    for (const Builder::Task& t : b.tasks) b.top_done[t.id] = 1;
-    b.finish_top(root);
     out.order.resize(n);
     team_run(b.team, [&](int t) {
         const uint32_t a = (uint32_t)((uint64_t)n * t / b.team), e = (uint32_t)((uint64_t)n * (t + 1) / b.team);
@@ -401,7 +384,7 @@ void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& 
     b.nodes.shrink(used);
     out.nodes = std::move(b.nodes);
     out.max_depth = b.max_depth.load();
-    if (prof) std::fprintf(stderr, "[zr] bvh: top %.1f ms (%zu tasks), subtrees %.1f ms, finish %.1f ms, team %d\n", (t1 - t0) * 1e3, b.tasks.size(), (t2 - t1) * 1e3, (now() - t2) * 1e3, b.team);
+    if (prof) std::fprintf(stderr, "[zr] bvh: tree %.1f ms, order %.1f ms, team %d\n", (t1 - t0) * 1e3, (now() - t2) * 1e3, b.team);
 }
 
 }  // namespace zr

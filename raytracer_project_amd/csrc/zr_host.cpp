@@ -14,7 +14,9 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zr_capi.h"
@@ -59,12 +61,14 @@ struct DevBuf {
     T* p = nullptr; size_t n = 0;
     ~DevBuf() { release(); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
-    int upload(const std::vector<T>& v) {
+    int upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
+    int upload(const zr::RawArray<T>& v) { return upload(v.data(), v.size()); }
+    int upload(const T* src, size_t count) {
         release();
-        n = v.size();
-        size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 64);  // never a null device pointer
+        n = count;
+        size_t bytes = std::max<size_t>(sizeof(T) * count, 64);  // never a null device pointer
         HIP_OK(hipMalloc((void**)&p, bytes));
-        if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+        if (count) HIP_OK(hipMemcpy(p, src, sizeof(T) * count, hipMemcpyHostToDevice));
         return ZR_OK;
     }
     int alloc(size_t count) {
@@ -266,55 +270,60 @@ int validate(const zr_scene& s, const std::vector<zr_object>& objs) {
     return ZR_OK;
 }
 
-// flattens the build tree into sibling-pair records and, leaf by leaf, the primitive arrays in leaf order
+// flattens the build tree into sibling-pair records and 4-wide nodes and, leaf by leaf, the primitive arrays in leaf order.
+// Built for commit latency like the builder (zr_bvh.cpp): one cheap serial walk fixes every index (pair numbers in pre-order,
+// each leaf's range in its kind's array), then the primitive records, the pair records and the 4-wide nodes (whose shape
+// depends on quantisation trials) are produced by all threads; nothing is appended under a lock.  The arrays are
+// zr::RawArray (no zero-fill).  The result is the same as a serial depth-first emit, whatever the number of threads.
 struct Flattener {
     const zr_scene& s;
     const std::vector<zr_object>& objs;
     const zr::BuildResult& br;
-    std::vector<zr::NodePair> pairs;
+    zr::RawArray<zr::NodePair> pairs;
     std::vector<zr::NodeQ> quads;
     std::vector<uint32_t> leaf_first;  // per build node: device index of a leaf's first primitive
     int quad_depth = 0;
-    std::vector<double> spheres, tri_v, tri_s, cubes, pcubes;
-    std::vector<uint32_t> sphere_mat, cube_mat, pcube_mat;
-    std::vector<zr::DMedium> media;
-    std::vector<zr::DWrapped> wrapped;
+    zr::RawArray<double> spheres, tri_v, tri_s, cubes, pcubes;
+    zr::RawArray<uint32_t> sphere_mat, cube_mat, pcube_mat;
+    zr::RawArray<zr::DMedium> media;
+    zr::RawArray<zr::DWrapped> wrapped;
+    size_t n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0;   // filled sizes (the arrays are sized exactly)
+    const std::vector<uint8_t>* baked = nullptr;   // per object: 0 as is, 1 baked triangle, 2 material-only chain, 3 baked sphere, 4 placed cube
+    size_t n_baked = 0;
+    int threads = 1;
 
+    template <class F>
+    void parallel_for(size_t n, size_t grain, F&& fn) const {   // fn(begin, end) over [0, n) split evenly
+        int T = threads;
+        if (n < 2 * grain) T = 1; else T = (int)std::min<size_t>((size_t)T, n / grain);
+        if (T <= 1) { fn((size_t)0, n); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back([&fn, n, t, T]() { fn(n * t / T, n * (t + 1) / T); });
+        fn((size_t)0, n / T);
+        for (auto& x : th) x.join();
+    }
+
+    // ---- one primitive record at a given index of its kind's array ------------------------------------------------------
     static constexpr uint32_t kKeepMaterial = 0xFFFFFFFEu;
     // `mat` != kKeepMaterial: the primitive sits under material_instance wrappers only, which do nothing but replace rec.mat
     // (material_instance.hpp:12-28) — it is stored bare with the outermost instance's material
-    uint32_t append_prim(uint32_t type, uint32_t idx, uint32_t mat = kKeepMaterial) {
-        switch (type) {
-            case ZR_PRIM_SPHERE: {
-                const double* q = &s.spheres[(size_t)idx * 4];
-                spheres.insert(spheres.end(), {q[0], q[1], q[2], std::fmax(0, q[3])});  // sphere.hpp:9
-                sphere_mat.push_back(mat != kKeepMaterial ? mat : s.sphere_mat[idx]);
-                return (uint32_t)sphere_mat.size() - 1;
-            }
-            case ZR_PRIM_TRIANGLE: {
-                tri_v.insert(tri_v.end(), &s.tri_v[(size_t)idx * 9], &s.tri_v[(size_t)idx * 9] + 9);
-                tri_s.insert(tri_s.end(), &s.tri_v[(size_t)idx * 9], &s.tri_v[(size_t)idx * 9] + 9);
-                tri_s.insert(tri_s.end(), &s.tri_n[(size_t)idx * 9], &s.tri_n[(size_t)idx * 9] + 9);
-                uint64_t mbits = s.tri_mat[idx];
-                double md; std::memcpy(&md, &mbits, 8);
-                tri_s.push_back(md); tri_s.push_back(0.0);
-                return (uint32_t)(tri_s.size() / 20) - 1;
-            }
-            case ZR_PRIM_CUBE: {
-                cubes.insert(cubes.end(), &s.cubes[(size_t)idx * 12], &s.cubes[(size_t)idx * 12] + 6);
-                cube_mat.push_back(mat != kKeepMaterial ? mat : s.cube_mat[idx]);
-                return (uint32_t)cube_mat.size() - 1;
-            }
-            default: {
-                const zr_medium& m = s.media[idx];
-                zr::DMedium d{};
-                d.btype = m.boundary_type; d.chain_first = m.chain_first; d.chain_count = m.chain_count;
-                d.mat = m.mat; d.id = idx; d.neg_inv_density = m.neg_inv_density;
-                d.bindex = append_prim(m.boundary_type, m.boundary_index);
-                media.push_back(d);
-                return (uint32_t)media.size() - 1;
-            }
-        }
+    void put_sphere(size_t di, uint32_t idx, uint32_t mat) {
+        const double* q = &s.spheres[(size_t)idx * 4];
+        double* d = &spheres[di * 4];
+        d[0] = q[0]; d[1] = q[1]; d[2] = q[2]; d[3] = std::fmax(0, q[3]);  // sphere.hpp:9
+        sphere_mat[di] = mat != kKeepMaterial ? mat : s.sphere_mat[idx];
+    }
+    void put_triangle_raw(size_t di, const double* v, const double* nn, uint32_t mat, bool force_front) {
+        std::memcpy(&tri_v[di * 9], v, 72);
+        double* t = &tri_s[di * 20];
+        std::memcpy(t, v, 72); std::memcpy(t + 9, nn, 72);
+        uint64_t mbits = mat, fbits = force_front ? 1u : 0u;
+        std::memcpy(t + 18, &mbits, 8); std::memcpy(t + 19, &fbits, 8);
+    }
+    void put_triangle(size_t di, uint32_t idx) { put_triangle_raw(di, &s.tri_v[(size_t)idx * 9], &s.tri_n[(size_t)idx * 9], s.tri_mat[idx], false); }
+    void put_cube(size_t di, uint32_t idx, uint32_t mat) {
+        std::memcpy(&cubes[di * 6], &s.cubes[(size_t)idx * 12], 48);
+        cube_mat[di] = mat != kKeepMaterial ? mat : s.cube_mat[idx];
     }
     // A triangle under a chain of translate / rotate_x,y,z / material_instance wrappers is stored in WORLD space as a bare
     // triangle: vertices and (un-normalised) vertex normals mapped object -> world with the wrappers' own forward maps
@@ -324,9 +333,7 @@ struct Flattener {
     // only the last bits of the hit differ from transforming the ray — and every mesh the reference's scenes place in the
     // world (model -> material_instance -> rotate -> translate) runs on the bare-triangle fast path instead of paying a
     // chain transform per candidate.  scale is excluded: it would change which triangles count as degenerate.
-    const std::vector<uint8_t>* baked = nullptr;   // per object
-    size_t n_baked = 0;
-    uint32_t append_baked_triangle(const zr_object& o) {
+    void put_baked_triangle(size_t di, const zr_object& o) {
         double v[9], nn[9];
         std::memcpy(v, &s.tri_v[(size_t)o.index * 9], sizeof v);
         std::memcpy(nn, &s.tri_n[(size_t)o.index * 9], sizeof nn);
@@ -351,19 +358,12 @@ struct Flattener {
             if (op.kind == ZR_OP_TRANSLATE || op.kind == ZR_OP_ROTATE_Y) force_front = true;
             if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
         }
-        tri_v.insert(tri_v.end(), v, v + 9);
-        tri_s.insert(tri_s.end(), v, v + 9);
-        tri_s.insert(tri_s.end(), nn, nn + 9);
-        uint64_t mbits = mat, fbits = force_front ? 1u : 0u;
-        double md, fd; std::memcpy(&md, &mbits, 8); std::memcpy(&fd, &fbits, 8);
-        tri_s.push_back(md); tri_s.push_back(fd);
-        n_baked++;
-        return (uint32_t)(tri_s.size() / 20) - 1;
+        put_triangle_raw(di, v, nn, mat, force_front);
     }
     // A sphere under uniform scale / translate / material_instance wrappers (the demo scene's instanced spheres:
     // scale -> material_instance -> translate) is the sphere (c s + offset, r s): same t, same unit normal, same u/v and
     // tangent (no rotation involved); bit 31 of its material word records the front_face = true a translate forces.
-    uint32_t append_baked_sphere(const zr_object& o) {
+    void put_baked_sphere(size_t di, const zr_object& o) {
         const double* q = &s.spheres[(size_t)o.index * 4];
         double c[3] = {q[0], q[1], q[2]}, r = std::fmax(0, q[3]);
         uint32_t mat = s.sphere_mat[o.index];
@@ -374,17 +374,16 @@ struct Flattener {
             else if (op.kind == ZR_OP_TRANSLATE) { c[0] += op.a[0]; c[1] += op.a[1]; c[2] += op.a[2]; force_front = true; }
             else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
         }
-        spheres.insert(spheres.end(), {c[0], c[1], c[2], r});
-        sphere_mat.push_back(force_front ? (mat | 0x80000000u) : mat);
-        n_baked++;
-        return (uint32_t)sphere_mat.size() - 1;
+        double* d = &spheres[di * 4];
+        d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = r;
+        sphere_mat[di] = force_front ? (mat | 0x80000000u) : mat;
     }
     // A cube under translate, or under rotate_y then translate (material_instance wrappers anywhere) — how every cube of the
     // reference's scenes is placed (scene_management.hpp:132-139, cfg5's walls and boxes) — is stored as a PLACED CUBE: the cube's
     // own numbers plus the two wrappers' parameters in one record.  The device applies the wrappers' ray and hit-record maps in the
     // chain's order with the chain's arithmetic (zr_device.h pcube_ray / object_rec), so results are those of the wrapped object;
     // what is saved is the op-list loop, its loads and the registers of the generic chain code in the traversal kernel.
-    uint32_t append_pcube(const zr_object& o) {
+    void put_pcube(size_t di, const zr_object& o) {
         const double* q = &s.cubes[(size_t)o.index * 12];
         double rec[12] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0};
         uint32_t mat = s.cube_mat[o.index];
@@ -394,63 +393,64 @@ struct Flattener {
             else if (op.kind == ZR_OP_ROTATE_Y) { rec[9] = op.a[0]; rec[10] = op.a[1]; rec[11] = 1.0; }
             else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
         }
-        pcubes.insert(pcubes.end(), rec, rec + 12);
-        pcube_mat.push_back(mat);
-        n_baked++;
-        return (uint32_t)pcube_mat.size() - 1;
+        std::memcpy(&pcubes[di * 12], rec, sizeof rec);
+        pcube_mat[di] = mat;
     }
-    // returns the first device index of the leaf's objects within its kind's array
-    uint32_t append_leaf(const zr::BuildNode& n) {
-        uint32_t first = 0;
-        for (uint32_t k = 0; k < n.count; k++) {
-            const uint32_t oi = br.order[n.first + k];
-            const zr_object& o = objs[oi];
-            uint32_t di;
-            if (baked && (*baked)[oi] == 1) {
-                di = append_baked_triangle(o);
-            } else if (baked && (*baked)[oi] == 3) {
-                di = append_baked_sphere(o);
-            } else if (baked && (*baked)[oi] == 4) {
-                di = append_pcube(o);
-            } else if (baked && (*baked)[oi] == 2) {
-                di = append_prim(o.type, o.index, s.ops[o.chain_first].mat);   // the outermost wrapper is applied last
-                n_baked++;
-            } else if (n.kind == ZR_KIND_WRAPPED) {
-                // reserve the slot order: inner primitives first would break contiguity of wrapped[] — it does not,
-                // wrapped[] only grows here
-                zr::DWrapped w{};
-                w.type = o.type; w.chain_first = o.chain_first; w.chain_count = o.chain_count;
-                w.index = append_prim(o.type, o.index);
-                wrapped.push_back(w);
-                di = (uint32_t)wrapped.size() - 1;
-            } else {
-                di = append_prim(o.type, o.index);
-            }
-            if (k == 0) first = di;
-        }
-        return first;
-    }
-    void set_child(uint32_t pair, int slot, int32_t node_id) {
-        const zr::BuildNode& n = br.nodes[node_id];
-        for (int k = 0; k < 3; k++) { pairs[pair].lo[slot][k] = f_down(n.box.lo[k]); pairs[pair].hi[slot][k] = f_up(n.box.hi[k]); }
-        if (n.count) {
-            uint32_t first = append_leaf(n);
-            leaf_first[node_id] = first;
-            pairs[pair].child[slot] = first;
-            pairs[pair].meta[slot] = ((n.kind + 1u) << 16) | n.count;
-        } else {
-            uint32_t c = emit_pair(node_id);
-            pairs[pair].child[slot] = c;
-            pairs[pair].meta[slot] = 0;
+    // object `oi` as a leaf primitive of a plain kind (sphere / triangle / cube / placed cube) at index di of that kind's array
+    void put_leaf_object(uint32_t oi, size_t di) {
+        const zr_object& o = objs[oi];
+        const uint8_t bk = baked ? (*baked)[oi] : 0;
+        if (bk == 1) put_baked_triangle(di, o);
+        else if (bk == 3) put_baked_sphere(di, o);
+        else if (bk == 4) put_pcube(di, o);
+        else {
+            const uint32_t mat = bk == 2 ? s.ops[o.chain_first].mat : kKeepMaterial;   // material-only chain: the outermost wrapper is applied last
+            if (o.type == ZR_PRIM_SPHERE) put_sphere(di, o.index, mat);
+            else if (o.type == ZR_PRIM_TRIANGLE) put_triangle(di, o.index);
+            else put_cube(di, o.index, mat);
         }
     }
-    uint32_t emit_pair(int32_t node_id) {
-        uint32_t p = (uint32_t)pairs.size();
-        pairs.push_back(zr::NodePair{});
-        const zr::BuildNode n = br.nodes[node_id];
-        set_child(p, 0, n.left);
-        set_child(p, 1, n.right);
-        return p;
+    // a primitive that is not a leaf object itself — a medium's boundary, the object inside a wrapper chain — goes behind the leaf
+    // ranges of its kind's array (serial: such objects are few)
+    uint32_t append_inner(uint32_t type, uint32_t idx) {
+        switch (type) {
+            case ZR_PRIM_SPHERE: put_sphere(n_sph, idx, kKeepMaterial); return (uint32_t)n_sph++;
+            case ZR_PRIM_TRIANGLE: put_triangle(n_tri, idx); return (uint32_t)n_tri++;
+            case ZR_PRIM_CUBE: put_cube(n_cube, idx, kKeepMaterial); return (uint32_t)n_cube++;
+            default: { const size_t di = n_media++; put_medium(di, idx); return (uint32_t)di; }
+        }
+    }
+    void put_medium(size_t di, uint32_t idx) {
+        const zr_medium& m = s.media[idx];
+        zr::DMedium d{};
+        d.btype = m.boundary_type; d.chain_first = m.chain_first; d.chain_count = m.chain_count;
+        d.mat = m.mat; d.id = idx; d.neg_inv_density = m.neg_inv_density;
+        d.bindex = append_inner(m.boundary_type, m.boundary_index);
+        media[di] = d;
+    }
+
+    // ---- the serial walk: pair numbers in pre-order, leaf ranges per kind, in the order a depth-first emit would visit them ----
+    std::vector<int32_t> inner;        // inner build nodes, position = pair index
+    std::vector<uint32_t> pair_of;     // per build node
+    std::vector<int32_t> leaves;       // leaf build nodes in emit order
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // leaf objects per kind
+    void walk(int32_t id) {
+        pair_of[id] = (uint32_t)inner.size(); inner.push_back(id);
+        const int32_t ch[2] = {br.nodes[id].left, br.nodes[id].right};
+        for (int k = 0; k < 2; k++) {
+            const zr::BuildNode& c = br.nodes[ch[k]];
+            if (c.count) { leaf_first[ch[k]] = cnt[c.kind & 7]; cnt[c.kind & 7] += c.count; leaves.push_back(ch[k]); }
+            else walk(ch[k]);
+        }
+    }
+    void fill_pair(uint32_t p, int32_t node_id) {
+        const int32_t ch[2] = {br.nodes[node_id].left, br.nodes[node_id].right};
+        for (int slot = 0; slot < 2; slot++) {
+            const zr::BuildNode& n = br.nodes[ch[slot]];
+            for (int k = 0; k < 3; k++) { pairs[p].lo[slot][k] = f_down(n.box.lo[k]); pairs[p].hi[slot][k] = f_up(n.box.hi[k]); }
+            if (n.count) { pairs[p].child[slot] = leaf_first[ch[slot]]; pairs[p].meta[slot] = ((n.kind + 1u) << 16) | n.count; }
+            else { pairs[p].child[slot] = pair_of[ch[slot]]; pairs[p].meta[slot] = 0; }
+        }
     }
     void empty_child(uint32_t pair, int slot) {
         for (int k = 0; k < 3; k++) { pairs[pair].lo[slot][k] = 0.f; pairs[pair].hi[slot][k] = 0.f; }
@@ -519,20 +519,24 @@ struct Flattener {
         }
         return true;
     }
-    bool quant_ok = true;  // false: a box below the root is not finite (the caller falls back to variant 0)
-    // emits the 4-wide node made of build node `node_id`; the root goes to `root` (FP32), everything else to `quads`
-    uint32_t emit_quad(int32_t node_id, int depth) {
-        const bool is_root = depth == 0;
-        quad_depth = std::max(quad_depth, depth);
-        int32_t kids[4]; int nk = 0;
+    std::atomic<bool> quant_ok_a{true};   // false: a box below the root is not finite (the caller falls back to variant 0)
+    bool quant_ok = true;
+    std::atomic<size_t> kept_closed_a{0};
+    // ---- 4-wide nodes.  Which children a node takes depends on quantisation trials, so a node's shape is only known once it is
+    // planned; planning is level-synchronous — every node of a level in parallel, the inner children forming the next level — and
+    // a serial pre-order walk then numbers the nodes and fills in the child references. ----
+    struct QuadPlan { int32_t kids[4]; int nk; zr::NodeQ nq; };
+    std::vector<QuadPlan> plan;          // per build node (only quad roots are filled)
+    void plan_quad(int32_t node_id, bool is_root, QuadPlan& qp) const {
+        int32_t* kids = qp.kids; int nk = 0;
         zr::NodeQ nq{};
         for (int ax = 0; ax < 3; ax++) nq.scale[ax] = 1;
-        if (node_id >= 0 && br.nodes[node_id].count) kids[nk++] = node_id;  // a world that is a single leaf
-        else if (node_id >= 0) {
+        if (br.nodes[node_id].count) kids[nk++] = node_id;  // a world that is a single leaf
+        else {
             nk = 2;
             kids[0] = br.nodes[node_id].left; kids[1] = br.nodes[node_id].right;
             double worst = 1;
-            if (!is_root && !quantise(kids, nk, nq, &worst)) quant_ok = false;
+            if (!is_root && !quantise(kids, nk, nq, &worst)) const_cast<Flattener*>(this)->quant_ok_a = false;
             while (nk < 4) {
                 // open the inner child with the largest area, unless the grid of the wider node would be too coarse
                 // for one of the boxes (then the child keeps its own node, whose grid fits its own children)
@@ -544,34 +548,67 @@ struct Flattener {
                 trial[best] = br.nodes[kids[best]].left; trial[nk] = br.nodes[kids[best]].right;
                 if (!is_root) {
                     zr::NodeQ tq = nq; double w = 1;
-                    if (!quantise(trial, nk + 1, tq, &w)) { quant_ok = false; break; }
-                    if (w > open_ratio && w > worst) { n_kept_closed++; break; }
+                    if (!quantise(trial, nk + 1, tq, &w)) { const_cast<Flattener*>(this)->quant_ok_a = false; break; }
+                    if (w > open_ratio && w > worst) { const_cast<Flattener*>(this)->kept_closed_a++; break; }
                     nq = tq; worst = w;
                 }
                 for (int k = 0; k <= nk; k++) kids[k] = trial[k];
                 nk++;
             }
         }
+        qp.nk = nk; qp.nq = nq;
+    }
+    // numbers the planned nodes in pre-order and writes them; the root goes to `root` (FP32), everything else to `quads`
+    uint32_t number_quad(int32_t node_id, int depth) {
+        const bool is_root = depth == 0;
+        quad_depth = std::max(quad_depth, depth);
+        const QuadPlan& qp = plan[node_id];
         uint32_t q = 0;
         if (!is_root) { q = (uint32_t)quads.size(); quads.push_back(zr::NodeQ{}); }
         uint32_t refs[4] = {ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY};
-        for (int k = 0; k < nk; k++) {
-            const zr::BuildNode& n = br.nodes[kids[k]];
-            if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[kids[k]];
-            else refs[k] = emit_quad(kids[k], depth + 1);
+        for (int k = 0; k < qp.nk; k++) {
+            const zr::BuildNode& n = br.nodes[qp.kids[k]];
+            if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[qp.kids[k]];
+            else refs[k] = number_quad(qp.kids[k], depth + 1);
         }
         if (is_root) {
-            for (int k = 0; k < nk; k++) {
-                const zr::BuildBox& bb = br.nodes[kids[k]].box;
+            for (int k = 0; k < qp.nk; k++) {
+                const zr::BuildBox& bb = br.nodes[qp.kids[k]].box;
                 root.lox[k] = f_down(bb.lo[0]); root.loy[k] = f_down(bb.lo[1]); root.loz[k] = f_down(bb.lo[2]);
                 root.hix[k] = f_up(bb.hi[0]); root.hiy[k] = f_up(bb.hi[1]); root.hiz[k] = f_up(bb.hi[2]);
             }
             for (int k = 0; k < 4; k++) root.ref[k] = refs[k];
             return 0;
         }
+        zr::NodeQ nq = qp.nq;
         for (int k = 0; k < 4; k++) nq.ref[k] = refs[k];
         quads[q] = nq;
         return q;
+    }
+    void build_quads(int32_t root_id) {
+        plan.resize(br.nodes.size());
+        std::vector<int32_t> level{root_id}, next;
+        bool first = true;
+        while (!level.empty()) {
+            const int T = std::max(1, threads);
+            std::vector<std::vector<int32_t>> out((size_t)T);
+            std::atomic<int> slot{0};
+            parallel_for(level.size(), 256, [&](size_t a, size_t b) {
+                std::vector<int32_t>& mine = out[(size_t)slot.fetch_add(1)];
+                for (size_t i = a; i < b; i++) {
+                    QuadPlan& qp = plan[level[i]];
+                    plan_quad(level[i], first, qp);
+                    for (int k = 0; k < qp.nk; k++) if (br.nodes[qp.kids[k]].count == 0) mine.push_back(qp.kids[k]);
+                }
+            });
+            next.clear();
+            for (auto& v : out) next.insert(next.end(), v.begin(), v.end());
+            level.swap(next);
+            first = false;
+        }
+        quads.reserve(inner.size() / 2 + 16);
+        number_quad(root_id, 0);
+        quant_ok = quant_ok_a.load(); n_kept_closed = kept_closed_a.load();
     }
     // Worst-case number of entries the EXTEND kernel's per-lane stack holds for this 4-wide tree: visiting a node whose
     // nk children are all hit pushes nk - 1 of them and descends into the nearest (any child can be the nearest), or
@@ -588,21 +625,82 @@ struct Flattener {
     }
     uint32_t stack_demand() const { return demand_of(root.ref); }
     void run() {
+        {
+            unsigned hw = std::thread::hardware_concurrency();
+            if (const char* e = std::getenv("ZR_BVH_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+            threads = (int)std::max(1u, std::min(32u, hw));
+        }
         leaf_first.assign(br.nodes.size(), 0);
+        if (baked) for (uint8_t b : *baked) if (b) n_baked++;
         if (br.nodes.empty()) {
-            pairs.push_back(zr::NodePair{}); empty_child(0, 0); empty_child(0, 1);
-            emit_quad(-1, 0);
+            pairs.allocate(1); empty_child(0, 0); empty_child(0, 1);
+            for (int k = 0; k < 4; k++) root.ref[k] = ZR_REF_EMPTY;
             return;
         }
-        if (br.nodes[0].count) {  // the whole world fits one leaf
-            pairs.push_back(zr::NodePair{});
-            set_child(0, 0, 0);
-            empty_child(0, 1);
-            emit_quad(0, 0);
-            return;
+        // 1. indices
+        pair_of.assign(br.nodes.size(), 0);
+        if (br.nodes[0].count) { leaf_first[0] = 0; cnt[br.nodes[0].kind & 7] = br.nodes[0].count; leaves.push_back(0); }   // the whole world fits one leaf
+        else { inner.reserve(br.nodes.size() / 2 + 1); leaves.reserve(br.nodes.size() / 2 + 1); walk(0); }
+        // 2. array sizes: the leaf ranges, then the primitives inside media and wrapper chains
+        size_t x_sph = 0, x_tri = 0, x_cube = 0, x_media = 0;
+        auto count_inner = [&](uint32_t type, uint32_t idx, auto&& self) -> void {
+            if (type == ZR_PRIM_SPHERE) x_sph++; else if (type == ZR_PRIM_TRIANGLE) x_tri++; else if (type == ZR_PRIM_CUBE) x_cube++;
+            else { x_media++; self(s.media[idx].boundary_type, s.media[idx].boundary_index, self); }
+        };
+        for (int32_t lf : leaves) {
+            const zr::BuildNode& n = br.nodes[lf];
+            if (n.kind != ZR_PRIM_MEDIUM && n.kind != ZR_KIND_WRAPPED) continue;
+            for (uint32_t k = 0; k < n.count; k++) {
+                const zr_object& o = objs[br.order[n.first + k]];
+                if (n.kind == ZR_PRIM_MEDIUM) count_inner(s.media[o.index].boundary_type, s.media[o.index].boundary_index, count_inner);
+                else count_inner(o.type, o.index, count_inner);
+            }
         }
-        emit_pair(0);
-        emit_quad(0, 0);
+        n_sph = cnt[ZR_PRIM_SPHERE]; n_tri = cnt[ZR_PRIM_TRIANGLE]; n_cube = cnt[ZR_PRIM_CUBE]; n_pcube = cnt[ZR_KIND_PCUBE];
+        n_media = cnt[ZR_PRIM_MEDIUM]; n_wrapped = cnt[ZR_KIND_WRAPPED];
+        spheres.allocate((n_sph + x_sph) * 4); sphere_mat.allocate(n_sph + x_sph);
+        tri_v.allocate((n_tri + x_tri) * 9); tri_s.allocate((n_tri + x_tri) * 20);
+        cubes.allocate((n_cube + x_cube) * 6); cube_mat.allocate(n_cube + x_cube);
+        pcubes.allocate(n_pcube * 12); pcube_mat.allocate(n_pcube);
+        media.allocate(n_media + x_media); wrapped.allocate(n_wrapped);
+        // 3. leaf primitives of the plain kinds: all threads
+        parallel_for(leaves.size(), 2048, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                const zr::BuildNode& n = br.nodes[leaves[i]];
+                if (n.kind == ZR_PRIM_MEDIUM || n.kind == ZR_KIND_WRAPPED) continue;
+                for (uint32_t k = 0; k < n.count; k++) put_leaf_object(br.order[n.first + k], (size_t)leaf_first[leaves[i]] + k);
+            }
+        });
+        // media and wrapped objects, with what they contain: serial, in emit order
+        for (int32_t lf : leaves) {
+            const zr::BuildNode& n = br.nodes[lf];
+            if (n.kind != ZR_PRIM_MEDIUM && n.kind != ZR_KIND_WRAPPED) continue;
+            for (uint32_t k = 0; k < n.count; k++) {
+                const zr_object& o = objs[br.order[n.first + k]];
+                const size_t di = (size_t)leaf_first[lf] + k;
+                if (n.kind == ZR_PRIM_MEDIUM) put_medium(di, o.index);
+                else {
+                    zr::DWrapped w{};
+                    w.type = o.type; w.chain_first = o.chain_first; w.chain_count = o.chain_count;
+                    w.index = append_inner(o.type, o.index);
+                    wrapped[di] = w;
+                }
+            }
+        }
+        // 4. pair records: all threads
+        if (inner.empty()) { pairs.allocate(1); fill_leaf_root(); }
+        else {
+            pairs.allocate(inner.size());
+            parallel_for(inner.size(), 4096, [&](size_t a, size_t b) { for (size_t p = a; p < b; p++) fill_pair((uint32_t)p, inner[p]); });
+        }
+        // 5. 4-wide nodes
+        build_quads(0);
+    }
+    void fill_leaf_root() {   // the whole world in one leaf: a pair whose second child is empty
+        const zr::BuildNode& n = br.nodes[0];
+        for (int k = 0; k < 3; k++) { pairs[0].lo[0][k] = f_down(n.box.lo[k]); pairs[0].hi[0][k] = f_up(n.box.hi[k]); }
+        pairs[0].child[0] = leaf_first[0]; pairs[0].meta[0] = ((n.kind + 1u) << 16) | n.count;
+        empty_child(0, 1);
     }
 };
 
@@ -896,7 +994,7 @@ int zr_scene_commit(zr_scene* s) {
     d.root = fl.root;
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         bool plain_media = true;   // media whose boundary is an unwrapped sphere or cube
-        for (const zr::DMedium& m : fl.media) if (m.chain_count != 0) plain_media = false;
+        for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) plain_media = false;
         if (!fl.wrapped.empty() || !plain_media) s->leaf_level = 2;
         else if (!fl.cubes.empty() || !fl.pcube_mat.empty() || !fl.media.empty()) s->leaf_level = 1;
         else s->leaf_level = 0;
