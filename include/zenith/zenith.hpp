@@ -1012,7 +1012,7 @@ inline shared_ptr<device_object> device_commit(shared_ptr<device_object>& cache,
     for (const auto& w : d->fs.warnings) std::cerr << "[zenith] " << w << "\n";
     d->sc = zr_scene_create(ctx);
     zr_scene_desc desc = d->fs.desc();
-    if (!d->sc || zr_scene_set_all(d->sc, &desc) != ZR_OK || zr_scene_commit(d->sc) != ZR_OK)
+    if (!d->sc || zr_scene_set_all_borrowed(d->sc, &desc) != ZR_OK || zr_scene_commit(d->sc) != ZR_OK)
         throw std::runtime_error(std::string(what) + ": " + zr_last_error());
     cache = d;
     return d;
@@ -1131,7 +1131,7 @@ public:
         if (!ctx) { std::cerr << "[zenith] render failed: " << zr_last_error() << "\n"; return; }
         zr_scene* sc = zr_scene_create(ctx);
         zr_scene_desc d = fs.desc();
-        int rc = sc ? zr_scene_set_all(sc, &d) : ZR_E_DEVICE;
+        int rc = sc ? zr_scene_set_all_borrowed(sc, &d) : ZR_E_DEVICE;
         if (rc == ZR_OK) rc = zr_scene_commit(sc);
         if (rc == ZR_OK) {
             zr_camera zc{};

@@ -171,8 +171,8 @@ typedef struct zr_counters {
     uint64_t media_tested;
     uint64_t hits;           /* segments that found a surface / medium event */
     uint64_t rng_draws;      /* main-stream draws */
-    /* wave-scheduler statistics (kernel variant 1): executions of the NODE / LEAF / SHADE phase and the lanes
-     * that were ready at each execution (lanes / (64 * execs) = SIMT utilisation of the phase) */
+    /* wave-scheduler statistics of the EXTEND kernel (counting build): executions of the NODE / LEAF phase and the lanes that were
+     * ready at each execution (lanes / (64 * execs) = SIMT utilisation of the phase); shade_* are unused by the pipeline */
     uint64_t node_execs, node_lanes, leaf_execs, leaf_lanes, shade_execs, shade_lanes;
     uint64_t rounds;         /* kernel variant 2: EXTEND/SHADE rounds of the last render */
     double extend_ms, shade_ms; /* kernel variant 2: device time of the EXTEND / SHADE launches of the last render */
@@ -227,6 +227,10 @@ int zr_scene_set_materials(zr_scene*, const zr_material*, size_t n);
 int zr_scene_set_textures(zr_scene*, const zr_texture*, size_t n, const void* texel_blob, size_t texel_bytes);
 /* all of the above in one call */
 int zr_scene_set_all(zr_scene*, const zr_scene_desc*);
+/* the same without the copies: the library keeps POINTERS to the geometry arrays of `desc` (spheres, triangles, cubes, media, ops,
+ * objects, texels — 216 MB for a million triangles) and reads them during the next zr_scene_commit, after which it forgets them.
+ * The caller keeps them valid and unchanged until that commit has returned.  The small tables (materials, textures) are copied. */
+int zr_scene_set_all_borrowed(zr_scene*, const zr_scene_desc*);
 /* builds the flattened BVH (replaces bvh_node's constructor, bvh.hpp:11-44) and uploads to HBM */
 int zr_scene_commit(zr_scene*);
 /* sizes of the committed scene: out[0]=bvh nodes (child-pair records), [1]=max depth, [2]=objects,

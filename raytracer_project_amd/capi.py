@@ -156,7 +156,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_set_all_borrowed", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_gather_frame", "zr_comm_destroy",
 ]
 
@@ -178,6 +178,7 @@ def load():
     lib.zr_scene_create.restype = vp; lib.zr_scene_create.argtypes = [vp]
     lib.zr_scene_destroy.argtypes = [vp]
     lib.zr_scene_set_all.argtypes = [vp, C.POINTER(SceneDesc)]
+    lib.zr_scene_set_all_borrowed.argtypes = [vp, C.POINTER(SceneDesc)]
     lib.zr_scene_set_spheres.argtypes = [vp, vp, vp, C.c_size_t]
     lib.zr_scene_set_triangles.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.zr_scene_set_cubes.argtypes = [vp, vp, vp, C.c_size_t]
@@ -368,7 +369,8 @@ class Scene:
         self._s = self.lib.zr_scene_create(ctx._c)
         if not self._s:
             raise ZrError(self.lib.zr_last_error().decode())
-        _check(self.lib.zr_scene_set_all(self._s, C.byref(desc)))
+        # the description's arrays outlive this call (the caller holds them): no need for the library to copy 200 MB of triangles
+        _check(self.lib.zr_scene_set_all_borrowed(self._s, C.byref(desc)))
         _check(self.lib.zr_scene_commit(self._s))
 
     def stats(self):

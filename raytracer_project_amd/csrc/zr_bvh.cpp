@@ -103,13 +103,16 @@ struct Builder {
     int team = 1;
     RawArray<Ref> refs, tmp;
     NodeArray nodes;
-    std::atomic<uint32_t> n_nodes{0};
     std::atomic<int> max_depth{0};
 
     explicit Builder(const std::vector<BuildBox>& b) : boxes(b) {}
 
     int cap_of(uint32_t kind) const { const int c = leaf_cap[kind & 7]; return c > 0 && c < max_leaf ? c : max_leaf; }
-    uint32_t alloc() { return n_nodes.fetch_add(1); }
+    // node ids without a shared counter: the subtree over `count` references rooted at node `id` owns the ids
+    // [id, id + 2 count - 1) — the left child is id + 1, the right child follows the left subtree's range.  A leaf of several
+    // objects leaves the rest of its range unused (the array is not zero-filled: untouched pages cost nothing).
+    static uint32_t left_id(uint32_t id) { return id + 1; }
+    static uint32_t right_id(uint32_t id, uint32_t left_count) { return id + 2 * left_count; }
     void note_depth(int d) { int cur = max_depth.load(); while (d > cur && !max_depth.compare_exchange_weak(cur, d)) {} }
 
     bool homogeneous(uint32_t first, uint32_t count) const {
@@ -306,7 +309,7 @@ struct Builder {
         FBox cbl, cbr;
         const uint32_t mid = split_node(id, first, count, depth, 1, cb, cbl, cbr);
         if (mid == first) return;
-        const uint32_t l = alloc(), r = alloc();
+        const uint32_t l = left_id(id), r = right_id(id, mid - first);
         nodes[id].left = (int32_t)l; nodes[id].right = (int32_t)r; nodes[id].count = 0; nodes[id].first = 0; nodes[id].kind = 0;
         build(l, first, mid - first, depth + 1, cbl);
         build(r, mid, first + count - mid, depth + 1, cbr);
@@ -322,7 +325,7 @@ struct Builder {
         const int par = count >= 4 * kTeamNode ? std::min(tm, (int)(count / (2 * kTeamNode))) : 1;
         const uint32_t mid = split_node(id, first, count, depth, par, cb, cbl, cbr);
         if (mid == first) return;
-        const uint32_t l = alloc(), r = alloc();
+        const uint32_t l = left_id(id), r = right_id(id, mid - first);
         nodes[id].left = (int32_t)l; nodes[id].right = (int32_t)r; nodes[id].count = 0; nodes[id].first = 0; nodes[id].kind = 0;
         const uint32_t lc = mid - first, rc = first + count - mid;
         int tl = (int)((uint64_t)tm * lc / count);
@@ -371,18 +374,16 @@ void build_bvh(const std::vector<BuildBox>& boxes, const std::vector<uint32_t>& 
     static const bool prof = std::getenv("ZR_BVH_PROFILE") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    const uint32_t root = b.alloc();
+    const uint32_t root = 0;
     b.nodes[root].left = b.nodes[root].right = -1; b.nodes[root].count = 0; b.nodes[root].first = 0; b.nodes[root].kind = 0;
     b.build_team(root, 0, n, 0, cb, b.team);
     double t1 = now(), t2 = t1;
-    const uint32_t used = b.n_nodes.load();
     out.order.resize(n);
     team_run(b.team, [&](int t) {
         const uint32_t a = (uint32_t)((uint64_t)n * t / b.team), e = (uint32_t)((uint64_t)n * (t + 1) / b.team);
         for (uint32_t i = a; i < e; i++) out.order[i] = b.refs[i].id;
     });
-    b.nodes.shrink(used);
-    out.nodes = std::move(b.nodes);
+    out.nodes = std::move(b.nodes);   // 2 n entries: ids are positions in the implicit layout, unused ones were never touched
     out.max_depth = b.max_depth.load();
     if (prof) std::fprintf(stderr, "[zr] bvh: tree %.1f ms, order %.1f ms, team %d\n", (t1 - t0) * 1e3, (now() - t2) * 1e3, b.team);
 }

@@ -89,10 +89,7 @@ struct zr_ctx {
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
-    DevBuf<unsigned int> d_task;          // task-queue head of the persistent kernel
-    DevBuf<unsigned char> d_overflow;     // per-wave BVH stack spill slabs
-    int wf_blocks = 0;
-    int variant = 2;                      // 0 pixel-group megakernel, 1 wave-scheduler megakernel, 2 streaming wavefront pipeline
+    int variant = 2;                      // 2 streaming wavefront pipeline (default); 0 pixel-group megakernel (the fallback for frames beyond the pipeline's packing limits)
     // variant 2: slot pool and per-frame buffers
     DevBuf<unsigned char> d_pool;
     DevBuf<uint32_t> d_pixels;
@@ -123,18 +120,36 @@ struct zr_ctx {
     bool last_counted = false;
 };
 
+// one input array of a scene: the library's own copy (zr_scene_set_*) or a view of the caller's memory (zr_scene_set_all_borrowed)
+template <class T>
+struct HostArray {
+    const T* p = nullptr; size_t n = 0;
+    std::vector<T> own;
+    void copy(const T* src, size_t count) { own.assign(src, src + count); p = own.data(); n = count; }
+    void borrow(const T* src, size_t count) { std::vector<T>().swap(own); p = src; n = count; }
+    void drop() { std::vector<T>().swap(own); p = nullptr; n = 0; }
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const T* data() const { return p; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+};
+
 struct zr_scene {
     zr_ctx* ctx = nullptr;
-    // host copies (as given)
-    std::vector<double> spheres, tri_v, tri_n, cubes;
-    std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
-    std::vector<zr_medium> media;
-    std::vector<zr_xform_op> ops;
-    std::vector<zr_object> objects;
+    // host side of the world as given: copies, or borrowed views until the commit
+    HostArray<double> spheres, tri_v, tri_n, cubes;
+    HostArray<uint32_t> sphere_mat, tri_mat, cube_mat;
+    HostArray<zr_medium> media;
+    HostArray<zr_xform_op> ops;
+    HostArray<zr_object> objects;
     bool objects_set = false;
+    bool borrowed = false;        // the geometry arrays are the caller's (released after the commit)
+    bool released = false;        // ... and have been released: the scene cannot be committed again without new input
     std::vector<zr_material> materials;
     std::vector<zr_texture> textures;
-    std::vector<unsigned char> texels;
+    HostArray<unsigned char> texels;
     // device
     bool committed = false;
     DevBuf<zr::NodePair> d_nodes;
@@ -526,7 +541,7 @@ struct Flattener {
     // planned; planning is level-synchronous — every node of a level in parallel, the inner children forming the next level — and
     // a serial pre-order walk then numbers the nodes and fills in the child references. ----
     struct QuadPlan { int32_t kids[4]; int nk; zr::NodeQ nq; };
-    std::vector<QuadPlan> plan;          // per build node (only quad roots are filled)
+    zr::RawArray<QuadPlan> plan;         // per build node (only quad roots are filled; not zero-filled)
     void plan_quad(int32_t node_id, bool is_root, QuadPlan& qp) const {
         int32_t* kids = qp.kids; int nk = 0;
         zr::NodeQ nq{};
@@ -586,7 +601,7 @@ struct Flattener {
         return q;
     }
     void build_quads(int32_t root_id) {
-        plan.resize(br.nodes.size());
+        plan.allocate(br.nodes.size());
         std::vector<int32_t> level{root_id}, next;
         bool first = true;
         while (!level.empty()) {
@@ -736,6 +751,7 @@ zr_ctx* zr_create(int device_ordinal) {
         }
     if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
     c->variant = (int)env_double("ZR_KERNEL", 2);
+    if (c->variant != 2) c->variant = 0;   // (variant 1, the round-1 wave-scheduler megakernel, is retired: 2-6 x slower and nothing depended on it)
     c->log_kind = (int)env_double("ZR_TIMELOG_KIND", 1);
     if (c->variant == 2) {
         c->st_blocks = zr::stream_extend_blocks();
@@ -751,12 +767,6 @@ zr_ctx* zr_create(int device_ordinal) {
             hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&c->h_active, (ST_MAX_POOLS + 1) * zr::stream_ctl_words() * sizeof(unsigned int), 0) != hipSuccess) { fail(ZR_E_DEVICE, "variant-2 buffers: out of memory"); delete c; return nullptr; }
     }
-    if (c->variant == 1) {
-        c->wf_blocks = zr::wavefront_max_blocks();
-        int over = (int)env_double("ZR_WF_BLOCKS", 0);
-        if (over > 0) c->wf_blocks = over;
-        if (c->d_task.alloc(1) != ZR_OK || c->d_overflow.alloc(zr::wavefront_overflow_bytes(c->wf_blocks)) != ZR_OK) { delete c; return nullptr; }
-    }
     return c;
 }
 
@@ -768,7 +778,6 @@ void zr_destroy(zr_ctx* c) {
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     c->d_ctr.release(); c->d_out.release(); c->d_tiles.release();
     c->d_pool.release(); c->d_pixels.release(); c->d_partial.release(); c->d_kend.release(); c->d_cls.release(); c->d_cpart.release(); c->d_ctl.release(); c->d_st_overflow.release();
-    c->d_task.release(); c->d_overflow.release();
     if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->st_event) (void)hipEventDestroy(c->st_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -788,42 +797,42 @@ void zr_scene_destroy(zr_scene* s) {
     delete s;
 }
 
-#define CHECK_SCENE(s) do { if (!(s)) return fail(ZR_E_INVALID, "null scene"); (s)->committed = false; } while (0)
+#define CHECK_SCENE(s) do { if (!(s)) return fail(ZR_E_INVALID, "null scene"); (s)->committed = false; (s)->released = false; } while (0)
 
 int zr_scene_set_spheres(zr_scene* s, const double* p, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!p || !mat)) return fail(ZR_E_INVALID, "null sphere arrays");
-    s->spheres.assign(p, p + n * 4); s->sphere_mat.assign(mat, mat + n);
+    s->spheres.copy(p, n * 4); s->sphere_mat.copy(mat, n);
     return ZR_OK;
 }
 int zr_scene_set_triangles(zr_scene* s, const double* v9, const double* n9, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!v9 || !n9 || !mat)) return fail(ZR_E_INVALID, "null triangle arrays");
-    s->tri_v.assign(v9, v9 + n * 9); s->tri_n.assign(n9, n9 + n * 9); s->tri_mat.assign(mat, mat + n);
+    s->tri_v.copy(v9, n * 9); s->tri_n.copy(n9, n * 9); s->tri_mat.copy(mat, n);
     return ZR_OK;
 }
 int zr_scene_set_cubes(zr_scene* s, const double* q, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!q || !mat)) return fail(ZR_E_INVALID, "null cube arrays");
-    s->cubes.assign(q, q + n * 12); s->cube_mat.assign(mat, mat + n);
+    s->cubes.copy(q, n * 12); s->cube_mat.copy(mat, n);
     return ZR_OK;
 }
 int zr_scene_set_media(zr_scene* s, const zr_medium* m, size_t n) {
     CHECK_SCENE(s);
     if (n && !m) return fail(ZR_E_INVALID, "null media array");
-    s->media.assign(m, m + n);
+    s->media.copy(m, n);
     return ZR_OK;
 }
 int zr_scene_set_xform_ops(zr_scene* s, const zr_xform_op* o, size_t n) {
     CHECK_SCENE(s);
     if (n && !o) return fail(ZR_E_INVALID, "null op array");
-    s->ops.assign(o, o + n);
+    s->ops.copy(o, n);
     return ZR_OK;
 }
 int zr_scene_set_objects(zr_scene* s, const zr_object* o, size_t n) {
     CHECK_SCENE(s);
     if (n && !o) return fail(ZR_E_INVALID, "null object array");
-    s->objects.assign(o, o + n); s->objects_set = n > 0;
+    s->objects.copy(o, n); s->objects_set = n > 0;
     return ZR_OK;
 }
 int zr_scene_set_materials(zr_scene* s, const zr_material* m, size_t n) {
@@ -836,7 +845,7 @@ int zr_scene_set_textures(zr_scene* s, const zr_texture* t, size_t n, const void
     CHECK_SCENE(s);
     if ((n && !t) || (bytes && !blob)) return fail(ZR_E_INVALID, "null texture arrays");
     s->textures.assign(t, t + n);
-    s->texels.assign((const unsigned char*)blob, (const unsigned char*)blob + bytes);
+    s->texels.copy((const unsigned char*)blob, bytes);
     return ZR_OK;
 }
 int zr_scene_set_all(zr_scene* s, const zr_scene_desc* d) {
@@ -853,13 +862,35 @@ int zr_scene_set_all(zr_scene* s, const zr_scene_desc* d) {
     return zr_scene_set_textures(s, d->textures, d->n_textures, d->texels, d->texel_bytes);
 }
 
+int zr_scene_set_all_borrowed(zr_scene* s, const zr_scene_desc* d) {
+    CHECK_SCENE(s);
+    if (!d) return fail(ZR_E_INVALID, "null scene description");
+    if ((d->n_spheres && (!d->spheres || !d->sphere_mat)) || (d->n_tris && (!d->tri_v || !d->tri_n || !d->tri_mat)) || (d->n_cubes && (!d->cubes || !d->cube_mat)) ||
+        (d->n_media && !d->media) || (d->n_ops && !d->ops) || (d->n_objects && !d->objects) || (d->texel_bytes && !d->texels))
+        return fail(ZR_E_INVALID, "null array in the scene description");
+    s->spheres.borrow(d->spheres, d->n_spheres * 4); s->sphere_mat.borrow(d->sphere_mat, d->n_spheres);
+    s->tri_v.borrow(d->tri_v, d->n_tris * 9); s->tri_n.borrow(d->tri_n, d->n_tris * 9); s->tri_mat.borrow(d->tri_mat, d->n_tris);
+    s->cubes.borrow(d->cubes, d->n_cubes * 12); s->cube_mat.borrow(d->cube_mat, d->n_cubes);
+    s->media.borrow(d->media, d->n_media);
+    s->ops.borrow(d->ops, d->n_ops);
+    s->objects.borrow(d->objects, d->n_objects); s->objects_set = d->n_objects > 0;
+    s->texels.borrow((const unsigned char*)d->texels, d->texel_bytes);
+    s->borrowed = true;
+    int rc;
+    if ((rc = zr_scene_set_materials(s, d->materials, d->n_materials))) return rc;   // the small tables are copied: render calls validate against them
+    if (d->n_textures && !d->textures) return fail(ZR_E_INVALID, "null texture array");
+    s->textures.assign(d->textures, d->textures + d->n_textures);
+    return ZR_OK;
+}
+
 int zr_scene_commit(zr_scene* s) {
     if (!s) return fail(ZR_E_INVALID, "null scene");
+    if (s->released) return fail(ZR_E_STATE, "the arrays given to zr_scene_set_all_borrowed were released by the previous commit: set the scene again");
     s->committed = false;
     HIP_OK(hipSetDevice(s->ctx->device));
     // the world list
     std::vector<zr_object> objs;
-    if (s->objects_set) objs = s->objects;
+    if (s->objects_set) objs.assign(s->objects.begin(), s->objects.end());
     else {
         std::vector<char> sb(s->sphere_mat.size(), 0), cb(s->cube_mat.size(), 0);
         for (const zr_medium& m : s->media) {
@@ -886,45 +917,58 @@ int zr_scene_commit(zr_scene* s) {
     std::vector<uint32_t> kinds(objs.size());
     std::vector<uint8_t> baked(objs.size(), 0);
     const bool bake = env_double("ZR_BAKE_TRIANGLES", 1) != 0;
-    for (size_t k = 0; k < objs.size(); k++) {
-        const zr_object& o = objs[k];
-        boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
-        kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
-        if (bake && o.type == ZR_PRIM_TRIANGLE && o.chain_count > 0) {   // see Flattener::append_baked_triangle
-            bool ok = true;
-            for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
-            if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
-        }
-        if (bake && o.type == ZR_PRIM_SPHERE && o.chain_count > 0) {   // see Flattener::append_baked_sphere
-            bool ok = true, moved = false; uint32_t mat = s->sphere_mat[o.index];
-            for (int q = (int)o.chain_count - 1; q >= 0 && ok; q--) {
-                const zr_xform_op& op = s->ops[o.chain_first + q];
-                if (op.kind == ZR_OP_SCALE) { ok = op.a[0] > 0 && op.a[0] == op.a[1] && op.a[1] == op.a[2]; moved = true; }
-                else if (op.kind == ZR_OP_TRANSLATE) moved = true;
-                else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
-                else ok = false;
+    std::atomic<size_t> bad_box{(size_t)-1};
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t nobj = objs.size();
+        const int T = nobj < 65536 ? 1 : (int)std::max(1u, std::min(16u, hw));
+        auto work = [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; k++) {
+            const zr_object& o = objs[k];
+            boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
+            kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
+            if (bake && o.type == ZR_PRIM_TRIANGLE && o.chain_count > 0) {   // see Flattener::append_baked_triangle
+                bool ok = true;
+                for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
+                if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
             }
-            if (ok && moved && mat < 0x7FFFFFFFu) { baked[k] = 3; kinds[k] = ZR_PRIM_SPHERE; }
-        }
-        if (bake && o.type == ZR_PRIM_CUBE && o.chain_count > 0) {   // see Flattener::append_pcube: [translate] or [translate, rotate_y], outermost first
-            int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
-            for (uint32_t q = 0; q < o.chain_count && ok; q++) {
-                const uint32_t kd = s->ops[o.chain_first + q].kind;
-                if (kd == ZR_OP_MATERIAL) continue;
-                if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
-                else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
-                else ok = false;
+            if (bake && o.type == ZR_PRIM_SPHERE && o.chain_count > 0) {   // see Flattener::append_baked_sphere
+                bool ok = true, moved = false; uint32_t mat = s->sphere_mat[o.index];
+                for (int q = (int)o.chain_count - 1; q >= 0 && ok; q--) {
+                    const zr_xform_op& op = s->ops[o.chain_first + q];
+                    if (op.kind == ZR_OP_SCALE) { ok = op.a[0] > 0 && op.a[0] == op.a[1] && op.a[1] == op.a[2]; moved = true; }
+                    else if (op.kind == ZR_OP_TRANSLATE) moved = true;
+                    else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+                    else ok = false;
+                }
+                if (ok && moved && mat < 0x7FFFFFFFu) { baked[k] = 3; kinds[k] = ZR_PRIM_SPHERE; }
             }
-            if (ok && pat >= 1) { baked[k] = 4; kinds[k] = ZR_KIND_PCUBE; }
+            if (bake && o.type == ZR_PRIM_CUBE && o.chain_count > 0) {   // see Flattener::append_pcube: [translate] or [translate, rotate_y], outermost first
+                int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
+                for (uint32_t q = 0; q < o.chain_count && ok; q++) {
+                    const uint32_t kd = s->ops[o.chain_first + q].kind;
+                    if (kd == ZR_OP_MATERIAL) continue;
+                    if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
+                    else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
+                    else ok = false;
+                }
+                if (ok && pat >= 1) { baked[k] = 4; kinds[k] = ZR_KIND_PCUBE; }
+            }
+            if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
+                bool only_material = true;
+                for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
+                if (only_material) { baked[k] = 2; kinds[k] = o.type; }
+            }
+            for (int a = 0; a < 3; a++)
+                if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) { size_t want = (size_t)-1; bad_box.compare_exchange_strong(want, k); }
         }
-        if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
-            bool only_material = true;
-            for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
-            if (only_material) { baked[k] = 2; kinds[k] = o.type; }
-        }
-        for (int a = 0; a < 3; a++)
-            if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", k);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, nobj * t / T, nobj * (t + 1) / T);
+        work(0, nobj / T);
+        for (auto& x : th) x.join();
     }
+    if (bad_box.load() != (size_t)-1) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", bad_box.load());
     zr::BuildResult br;
     double ck[8] = {env_double("ZR_BVH_COST_SPHERE", 1.0), env_double("ZR_BVH_COST_TRI", 1.5), env_double("ZR_BVH_COST_CUBE", 1.0),
                     env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), env_double("ZR_BVH_COST_PCUBE", 1.5), 1, 1};
@@ -958,7 +1002,7 @@ int zr_scene_commit(zr_scene* s) {
     if ((rc = s->d_pcube_mat.upload(fl.pcube_mat))) return rc;
     if ((rc = s->d_media.upload(fl.media))) return rc;
     if ((rc = s->d_wrapped.upload(fl.wrapped))) return rc;
-    if ((rc = s->d_ops.upload(s->ops))) return rc;
+    if ((rc = s->d_ops.upload(s->ops.data(), s->ops.size()))) return rc;
     {
         // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
         // texture tree, or a bump map) -> the kernels compute those hit-record fields only then
@@ -978,7 +1022,7 @@ int zr_scene_commit(zr_scene* s) {
         if ((rc = s->d_mats.upload(mats))) return rc;
     }
     if ((rc = s->d_texs.upload(s->textures))) return rc;
-    if ((rc = s->d_texels.upload(s->texels))) return rc;
+    if ((rc = s->d_texels.upload(s->texels.data(), s->texels.size()))) return rc;
 
     zr::DScene& d = s->ds;
     d.nodes = s->d_nodes.p; d.quads = s->d_quads.p;
@@ -1007,6 +1051,10 @@ int zr_scene_commit(zr_scene* s) {
     s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size() + fl.pcubes.size()) * 8 +
                   (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
     s->committed = true;
+    if (s->borrowed) {   // the caller's arrays are not read again: forget them (a second commit needs a new zr_scene_set_*)
+        s->spheres.drop(); s->sphere_mat.drop(); s->tri_v.drop(); s->tri_n.drop(); s->tri_mat.drop(); s->cubes.drop(); s->cube_mat.drop();
+        s->media.drop(); s->ops.drop(); s->objects.drop(); s->texels.drop(); s->objects_set = false; s->borrowed = false; s->released = true;
+    }
     phase("upload");
     return ZR_OK;
 }
@@ -1172,7 +1220,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     if (n_pix == 0) return ZR_OK;
     const uint32_t spp = (uint32_t)dc.spp;
     const uint64_t units = (uint64_t)n_pix * spp;   // one work unit per primary sample
-    if (units > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x spp must fit 32 bits); shard it or set ZR_KERNEL=1");
+    if (units > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x spp must fit 32 bits); shard it (zr_region) or set ZR_KERNEL=0");
     // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
     // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
     uint32_t P = c->st_slots / 64 * 64;
@@ -1263,10 +1311,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         zr_ctx::Pending pe{}; pe.render_id = c->render_id; pe.kind = 1;
         if ((rc = get_event(pe.a)) || (rc = get_event(pe.b))) return rc;
         HIP_OK(hipEventRecord(pe.a, stream));
-        if (c->variant == 1)
-            HIP_OK(zr::launch_render_wavefront(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, c->d_task.p, c->d_overflow.p, c->wf_blocks, stream));
-        else
-            HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
+        HIP_OK(zr::launch_render(s->ds, dc, de, seed, wd, d_out, c->d_ctr.p, count != 0, stream));
         HIP_OK(hipEventRecord(pe.b, stream));
         c->pending.push_back(pe);
         if (keep_going || rows_done) {

@@ -23,12 +23,6 @@ struct WorkDesc {
 
 hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
                          unsigned long long* gctr, bool count, hipStream_t stream);
-// variant 1: persistent wave-scheduler kernel (zr_wavefront.hip)
-size_t wavefront_overflow_bytes(int blocks);
-int wavefront_max_blocks();
-hipError_t launch_render_wavefront(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
-                                   unsigned long long* gctr, bool count, unsigned int* task_counter, void* overflow, int max_blocks,
-                                   hipStream_t stream);
 // variant 2: streaming wavefront pipeline (zr_stream.hip)
 struct StreamTimer {  // host-provided HIP-event recorder; kind: 0 init, 1 extend, 2 shade, 3 reduce
     virtual void begin(hipStream_t, int kind) = 0;
