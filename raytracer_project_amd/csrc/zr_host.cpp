@@ -573,56 +573,81 @@ struct Flattener {
         }
         qp.nk = nk; qp.nq = nq;
     }
-    // numbers the planned nodes in pre-order and writes them; the root goes to `root` (FP32), everything else to `quads`
-    uint32_t number_quad(int32_t node_id, int depth) {
-        const bool is_root = depth == 0;
-        quad_depth = std::max(quad_depth, depth);
-        const QuadPlan& qp = plan[node_id];
-        uint32_t q = 0;
-        if (!is_root) { q = (uint32_t)quads.size(); quads.push_back(zr::NodeQ{}); }
-        uint32_t refs[4] = {ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY};
-        for (int k = 0; k < qp.nk; k++) {
-            const zr::BuildNode& n = br.nodes[qp.kids[k]];
-            if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[qp.kids[k]];
-            else refs[k] = number_quad(qp.kids[k], depth + 1);
-        }
-        if (is_root) {
-            for (int k = 0; k < qp.nk; k++) {
-                const zr::BuildBox& bb = br.nodes[qp.kids[k]].box;
-                root.lox[k] = f_down(bb.lo[0]); root.loy[k] = f_down(bb.lo[1]); root.loz[k] = f_down(bb.lo[2]);
-                root.hix[k] = f_up(bb.hi[0]); root.hiy[k] = f_up(bb.hi[1]); root.hiz[k] = f_up(bb.hi[2]);
-            }
-            for (int k = 0; k < 4; k++) root.ref[k] = refs[k];
-            return 0;
-        }
-        zr::NodeQ nq = qp.nq;
-        for (int k = 0; k < 4; k++) nq.ref[k] = refs[k];
-        quads[q] = nq;
-        return q;
-    }
-    void build_quads(int32_t root_id) {
+    // Numbering: pre-order, as a serial depth-first emit would number them — node index = parent's index + 1 + the sizes of the
+    // subtrees of its earlier inner siblings (the root has none: its first child is node 0).  Subtree sizes come from a pass over the
+    // planned levels bottom-up, indices from a pass top-down, the records are written by all threads.
+    std::vector<std::vector<int32_t>> levels;     // planned quad roots, level by level (levels[0] = {root})
+    zr::RawArray<uint32_t> q_size, q_index;       // per build node: quads in its subtree (itself included), its own index
+    void plan_quads(int32_t root_id) {
         plan.allocate(br.nodes.size());
-        std::vector<int32_t> level{root_id}, next;
+        levels.clear();
+        levels.push_back(std::vector<int32_t>{root_id});
         bool first = true;
-        while (!level.empty()) {
+        for (;;) {
+            const std::vector<int32_t>& level = levels.back();
             const int T = std::max(1, threads);
             std::vector<std::vector<int32_t>> out((size_t)T);
             std::atomic<int> slot{0};
-            parallel_for(level.size(), 256, [&](size_t a, size_t b) {
+            parallel_for(level.size(), 256, [&](size_t a2, size_t b2) {
                 std::vector<int32_t>& mine = out[(size_t)slot.fetch_add(1)];
-                for (size_t i = a; i < b; i++) {
+                for (size_t i = a2; i < b2; i++) {
                     QuadPlan& qp = plan[level[i]];
                     plan_quad(level[i], first, qp);
                     for (int k = 0; k < qp.nk; k++) if (br.nodes[qp.kids[k]].count == 0) mine.push_back(qp.kids[k]);
                 }
             });
-            next.clear();
+            std::vector<int32_t> next;
             for (auto& v : out) next.insert(next.end(), v.begin(), v.end());
-            level.swap(next);
             first = false;
+            if (next.empty()) break;
+            levels.push_back(std::move(next));
         }
-        quads.reserve(inner.size() / 2 + 16);
-        number_quad(root_id, 0);
+    }
+    void number_quads(int32_t root_id) {
+        q_size.allocate(br.nodes.size()); q_index.allocate(br.nodes.size());
+        for (size_t l = levels.size(); l-- > 0;) {   // bottom-up: subtree sizes
+            const std::vector<int32_t>& level = levels[l];
+            parallel_for(level.size(), 2048, [&](size_t a2, size_t b2) {
+                for (size_t i = a2; i < b2; i++) {
+                    const QuadPlan& qp = plan[level[i]];
+                    uint32_t n = 1;
+                    for (int k = 0; k < qp.nk; k++) if (br.nodes[qp.kids[k]].count == 0) n += q_size[qp.kids[k]];
+                    q_size[level[i]] = n;
+                }
+            });
+        }
+        const size_t n_quads = (size_t)q_size[root_id] - 1;   // the root travels in the kernel arguments
+        q_index[root_id] = 0xFFFFFFFFu;                        // so that its first child becomes node 0
+        quads.resize(n_quads);
+        for (size_t l = 0; l < levels.size(); l++) {           // top-down: indices, and the records themselves
+            const std::vector<int32_t>& level = levels[l];
+            parallel_for(level.size(), 1024, [&](size_t a2, size_t b2) {
+                for (size_t i = a2; i < b2; i++) {
+                    const int32_t node_id = level[i];
+                    const QuadPlan& qp = plan[node_id];
+                    uint32_t refs[4] = {ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY, ZR_REF_EMPTY};
+                    uint32_t next = q_index[node_id] + 1u;
+                    for (int k = 0; k < qp.nk; k++) {
+                        const zr::BuildNode& n = br.nodes[qp.kids[k]];
+                        if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[qp.kids[k]];
+                        else { refs[k] = next; q_index[qp.kids[k]] = next; next += q_size[qp.kids[k]]; }
+                    }
+                    if (l == 0) {
+                        for (int k = 0; k < qp.nk; k++) {
+                            const zr::BuildBox& bb = br.nodes[qp.kids[k]].box;
+                            root.lox[k] = f_down(bb.lo[0]); root.loy[k] = f_down(bb.lo[1]); root.loz[k] = f_down(bb.lo[2]);
+                            root.hix[k] = f_up(bb.hi[0]); root.hiy[k] = f_up(bb.hi[1]); root.hiz[k] = f_up(bb.hi[2]);
+                        }
+                        for (int k = 0; k < 4; k++) root.ref[k] = refs[k];
+                    } else {
+                        zr::NodeQ nq = qp.nq;
+                        for (int k = 0; k < 4; k++) nq.ref[k] = refs[k];
+                        quads[q_index[node_id]] = nq;
+                    }
+                }
+            });
+        }
+        quad_depth = (int)levels.size() - 1;
         quant_ok = quant_ok_a.load(); n_kept_closed = kept_closed_a.load();
     }
     // Worst-case number of entries the EXTEND kernel's per-lane stack holds for this 4-wide tree: visiting a node whose
@@ -640,6 +665,10 @@ struct Flattener {
     }
     uint32_t stack_demand() const { return demand_of(root.ref); }
     void run() {
+        const bool stats = std::getenv("ZR_COMMIT_STATS") != nullptr;
+        auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_ph = now_s();
+        auto ph = [&](const char* what) { if (stats) { const double t = now_s(); std::fprintf(stderr, "[zr] flatten: %-18s %.1f ms\n", what, (t - t_ph) * 1e3); t_ph = t; } };
         {
             unsigned hw = std::thread::hardware_concurrency();
             if (const char* e = std::getenv("ZR_BVH_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
@@ -656,6 +685,7 @@ struct Flattener {
         pair_of.assign(br.nodes.size(), 0);
         if (br.nodes[0].count) { leaf_first[0] = 0; cnt[br.nodes[0].kind & 7] = br.nodes[0].count; leaves.push_back(0); }   // the whole world fits one leaf
         else { inner.reserve(br.nodes.size() / 2 + 1); leaves.reserve(br.nodes.size() / 2 + 1); walk(0); }
+        ph("index walk");
         // 2. array sizes: the leaf ranges, then the primitives inside media and wrapper chains
         size_t x_sph = 0, x_tri = 0, x_cube = 0, x_media = 0;
         auto count_inner = [&](uint32_t type, uint32_t idx, auto&& self) -> void {
@@ -686,6 +716,7 @@ struct Flattener {
                 for (uint32_t k = 0; k < n.count; k++) put_leaf_object(br.order[n.first + k], (size_t)leaf_first[leaves[i]] + k);
             }
         });
+        ph("primitive records");
         // media and wrapped objects, with what they contain: serial, in emit order
         for (int32_t lf : leaves) {
             const zr::BuildNode& n = br.nodes[lf];
@@ -702,14 +733,19 @@ struct Flattener {
                 }
             }
         }
+        ph("media / wrapped");
         // 4. pair records: all threads
         if (inner.empty()) { pairs.allocate(1); fill_leaf_root(); }
         else {
             pairs.allocate(inner.size());
             parallel_for(inner.size(), 4096, [&](size_t a, size_t b) { for (size_t p = a; p < b; p++) fill_pair((uint32_t)p, inner[p]); });
         }
+        ph("pair records");
         // 5. 4-wide nodes
-        build_quads(0);
+        plan_quads(0);
+        ph("4-wide plan");
+        number_quads(0);
+        ph("4-wide numbering");
     }
     void fill_leaf_root() {   // the whole world in one leaf: a pair whose second child is empty
         const zr::BuildNode& n = br.nodes[0];
