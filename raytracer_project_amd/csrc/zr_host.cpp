@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -1092,6 +1093,17 @@ int zr_scene_commit(zr_scene* s) {
         s->media.drop(); s->ops.drop(); s->objects.drop(); s->texels.drop(); s->objects_set = false; s->borrowed = false; s->released = true;
     }
     phase("upload");
+    {   // unmapping half a gigabyte of staging arrays takes tens of milliseconds: not on the caller's clock
+        struct Trash { zr::BuildResult br; zr::RawArray<zr::NodePair> pairs; zr::RawArray<double> a, b, c, d, e; zr::RawArray<uint32_t> f, g, h; std::vector<zr::NodeQ> quads;
+                       zr::RawArray<uint32_t> qs, qi; std::vector<zr::BuildBox> boxes; std::vector<zr_object> objs; };
+        auto t = std::make_shared<Trash>();
+        t->br = std::move(br); t->pairs = std::move(fl.pairs); t->a = std::move(fl.spheres); t->b = std::move(fl.tri_v); t->c = std::move(fl.tri_s); t->d = std::move(fl.cubes);
+        t->e = std::move(fl.pcubes); t->f = std::move(fl.sphere_mat); t->g = std::move(fl.cube_mat); t->h = std::move(fl.pcube_mat); t->quads = std::move(fl.quads);
+        t->qs = std::move(fl.q_size); t->qi = std::move(fl.q_index); t->boxes = std::move(boxes); t->objs = std::move(objs);
+        fl.plan.clear();   // never touched beyond the planned nodes' pages: cheap
+        try { std::thread([t]() mutable { t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
+    }
+    phase("release");
     return ZR_OK;
 }
 
