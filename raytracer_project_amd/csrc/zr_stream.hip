@@ -49,7 +49,7 @@ namespace zr {
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
-#define ST_LDS_STACK 12
+#define ST_LDS_STACK 11
 #endif
 
 enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18,
@@ -147,13 +147,36 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
 // Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
 // host sizes the slab from the exact worst-case demand of the committed tree (Flattener::stack_demand), so no push can
 // leave it.
+// Workgroup = ST_EXT_GROUP waves that share nothing but the LDS copy of the tree's first levels (DScene::top, at most
+// ZR_TOP_MAX nodes, 80-byte stride so that lanes reading different nodes spread over the banks): every wave keeps its own
+// stack slice, ray chunks and state machine, and after the barrier that publishes the copy no wave waits for another.
+// Why: the kernel's time follows the number of divergent 16-byte requests its lanes put through the vector memory pipe
+// (one more 4-byte request per node visit, of bytes already being fetched: +10.6 %, profiles/r2_experiments_ab.txt) —
+// and the first levels take 2 of a ray's 4-5 node visits.
+#ifndef ST_EXT_GROUP
+#define ST_EXT_GROUP 8
+#endif
+#define ST_TOP_STRIDE 20  /* dwords */
 template <bool COUNT, int LEVEL>
-__global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
+__global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
                                                                   uint32_t ovf_levels, unsigned long long* __restrict__ gctr) {
-    __shared__ SEntry lstack[ST_LDS_STACK * 64];
-    const int lane = threadIdx.x;
+    __shared__ SEntry lstack[ST_EXT_GROUP * ST_LDS_STACK * 64];
+#ifndef ZR_EXT_NO_TOP
+    __shared__ __attribute__((aligned(16))) uint32_t ltop[ZR_TOP_MAX * ST_TOP_STRIDE];
+#endif
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = blockIdx.x * ST_EXT_GROUP + (threadIdx.x >> 6);
+    const int lbase = (int)(threadIdx.x >> 6) * ST_LDS_STACK * 64 + lane;   // this lane's column of this wave's stack slice
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    SEntry* gstack = overflow + (size_t)blockIdx.x * ovf_levels * 64 + lane;
+    SEntry* gstack = overflow + (size_t)wave_id * ovf_levels * 64 + lane;
+#ifndef ZR_EXT_NO_TOP
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.top);
+        const uint32_t n = (sc.n_top < ZR_TOP_MAX ? sc.n_top : ZR_TOP_MAX) * 16u;
+        for (uint32_t i = threadIdx.x; i < n; i += 64 * ST_EXT_GROUP) ltop[(i >> 4) * ST_TOP_STRIDE + (i & 15u)] = src[i];
+        __syncthreads();
+    }
+#endif
     const double INF = __builtin_huge_val();
     const float INFf = __builtin_huge_valf();
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -172,8 +195,8 @@ __global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EX
     Rng g; g.key = 0; g.k = 0; g.bounce = 0;  // only the medium test reads it
     bool work_left = true;
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the private range of ray indices being handed out
-    uint32_t head_shard = blockIdx.x % ST_SHARDS, shards_tried = 0;
-    if (blockIdx.x == 0 && lane < ST_SHARDS) B.ctl[16 + 32 * lane + 16] = 0;  // SHADE of this round recounts the active slots
+    uint32_t head_shard = wave_id % ST_SHARDS, shards_tried = 0;
+    if (wave_id == 0 && lane < ST_SHARDS) B.ctl[16 + 32 * lane + 16] = 0;  // SHADE of this round recounts the active slots
     uint32_t c_nodes = 0, c_sph = 0, c_tri = 0, c_cube = 0, c_med = 0, c_seg = 0, c_hits = 0;
     unsigned long long s_exec[2] = {0, 0}, s_lanes[2] = {0, 0};
 
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EX
 #define ZR_PUSH(REF, TN)                                                                                        \
     {                                                                                                           \
         SEntry e_; e_.node = (REF); e_.tn = (TN);                                                               \
-        if (sp < ZR_LDS_LEVELS) lstack[sp * 64 + lane] = e_; else gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64] = e_; \
+        if (sp < ZR_LDS_LEVELS) lstack[sp * 64 + lbase] = e_; else gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64] = e_; \
         sp++;                                                                                                   \
     }
 // nearest deferred entry that can still matter, else the ray is done
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EX
         if (sp == 0) { finish(); break; }                                                                       \
         sp--;                                                                                                   \
         SEntry e_;                                                                                              \
-        if (sp < ZR_LDS_LEVELS) e_ = lstack[sp * 64 + lane]; else e_ = gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64]; \
+        if (sp < ZR_LDS_LEVELS) e_ = lstack[sp * 64 + lbase]; else e_ = gstack[(size_t)(sp - ZR_LDS_LEVELS) * 64]; \
         if (e_.tn <= tbest_f) { cur = e_.node; pend_i = 0; st = (e_.node & X_LEAF_BIT) ? X_LEAF : X_NODE; break; } \
     }
 
@@ -277,11 +300,20 @@ __global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EX
             if (st == X_IDLE) {
                 const uint32_t my = base + (uint32_t)__popcll(idle & lt_mask);
                 if (my < lim) {
+                    // LEVEL > 0: meta word and ray requested together, one memory round trip per refill instead of two (an inactive
+                    // slot's ray row is addressable like any other): cfg5 -1 %.  The lean build has no registers to hold the ray
+                    // while the meta word is tested (2 more spilled, cfg3 +3 %): it asks for the ray once the slot is known active.
                     const uint2 m = B.ld2(SF_MA, my);
+                    V3 ro_ = mk(0, 0, 0), rd_ = mk(0, 0, 0);
+                    double key_ = 0;
+                    if (LEVEL > 0) {
+                        ro_ = B.ld3(SF_RAY, my); rd_ = B.ld3(SF_RAY + 3, my); key_ = B.ld(SF_KEY, my);
+                        asm volatile("" ::"v"(ro_.x), "v"(rd_.z), "v"(key_));   // keeps the requests above the branch
+                    }
                     if (m.y & F_ACTIVE) {
                         slot = my;
-                        ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my);
-                        if (LEVEL > 0) { g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, my)); g.bounce = m.y & 0xFFu; }
+                        if (LEVEL > 0) { ray.o = ro_; ray.d = rd_; } else { ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my); }
+                        if (LEVEL > 0) { g.key = (uint64_t)__double_as_longlong(key_); g.bounce = m.y & 0xFFu; }
                         {
                             const float NANf = __builtin_nanf("");
                             idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
@@ -317,8 +349,18 @@ __global__ __launch_bounds__(64, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EX
             if (st == X_NODE) {
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
-                const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
-                const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
+                uint4 w0, w1, w2, ref;
+#ifndef ZR_EXT_NO_TOP
+                if (cur & ZR_REF_TOP) {   // one of the first levels' nodes: from the workgroup's LDS copy
+                    const uint4* lq = reinterpret_cast<const uint4*>(&ltop[(cur & 0xFFFFu) * ST_TOP_STRIDE]);
+                    w0 = lq[0]; w1 = lq[1]; w2 = lq[2]; ref = lq[3];
+                } else
+#endif
+                {
+                    // (a build without the LDS copy reads such a node from the copy's source)
+                    const uint4* nq = reinterpret_cast<const uint4*>((cur & ZR_REF_TOP) ? sc.top + (cur & 0xFFFFu) : sc.quads + cur);
+                    w0 = nq[0]; w1 = nq[1]; w2 = nq[2]; ref = nq[3];
+                }
                 // t = fmaf(q, a, b): a = scale * id, b = the node origin's parametric distance (the lower planes' b moved
                 // by -2^-15 a, the upper planes' by +2^-15 a: towards "earlier" resp. "later" whatever the sign of id)
                 const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
@@ -423,29 +465,34 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     // unsorted, almost every wave of a mixed scene runs every branch.  A counting sort through LDS: per-wave ballots per class,
     // a 4 x 8 table of counts, ranks by prefix popcount.  The material lookup it needs (primitive -> material id -> kind) is
     // the first access of the lines the hit record reads anyway; a scene with a single material kind skips it (hit / miss only).
-    __shared__ unsigned char perm[256];
+    // The whole kernel is a chain of dependent memory round trips (73 % of its wave cycles sit in s_waitcnt, SQ counters of
+    // round 2), so the rows a segment needs are requested as early and as much at once as their addresses are known:
+    // the slot's meta word and its hit together; the sort hands both through LDS to the thread that will shade the slot (no
+    // second read); that thread requests every state row of the segment in one go.
     __shared__ unsigned int wave_cls[4][8];
+    __shared__ uint4 x_mk[256];          // (meta.x, meta.y, hit kind, hit index) of the slot a thread will shade
+    __shared__ unsigned char x_src[256]; // ... and which slot of the block that is
     uint32_t slot;
-#ifdef ZR_SHADE_NO_PARTITION
-    slot = slot0;
-#else
+    uint2 m, ki;
     {
+        uint2 m0; m0.x = 0; m0.y = 0;
+        uint2 k0; k0.x = 0xFFFFFFFFu; k0.y = 0;
+        if (slot0 < B.P) { m0 = B.ld2(SF_MA, slot0); k0 = B.ld2(SF_HIT_KI, slot0); }
+#ifdef ZR_SHADE_NO_PARTITION
+        slot = slot0; m = m0; ki = k0;
+#else
         uint32_t cls = 7;
-        if (slot0 < B.P) {
-            const uint2 m0 = B.ld2(SF_MA, slot0);
-            if (m0.y & F_ACTIVE) {
-                const uint2 k0 = B.ld2(SF_HIT_KI, slot0);
-                if (k0.x == 0xFFFFFFFFu) cls = 6;
-                else {
-                    cls = 0;
+        if (m0.y & F_ACTIVE) {
+            if (k0.x == 0xFFFFFFFFu) cls = 6;
+            else {
+                cls = 0;
 #ifndef ZR_SHADE_HITMISS_ONLY
-                    if (sc.mat_kinds & (sc.mat_kinds - 1u)) {   // more than one material kind in the scene (wave-uniform)
-                        const uint32_t mat = object_material(sc, k0.x, k0.y);
-                        cls = mat < sc.n_mats ? sc.mats[mat].kind : 5u;
-                        if (cls > 5u) cls = 5u;
-                    }
-#endif
+                if (sc.mat_kinds & (sc.mat_kinds - 1u)) {   // more than one material kind in the scene (wave-uniform)
+                    const uint32_t mat = object_material(sc, k0.x, k0.y);
+                    cls = mat < sc.n_mats ? sc.mats[mat].kind : 5u;
+                    if (cls > 5u) cls = 5u;
                 }
+#endif
             }
         }
         const int w = threadIdx.x >> 6, wl = threadIdx.x & 63;
@@ -462,27 +509,51 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
         for (uint32_t c = 0; c < 8; c++)
             for (int k = 0; k < 4; k++)
                 if (c < cls || (c == cls && k < w)) base += wave_cls[k][c];
-        perm[base + my_rank] = (unsigned char)threadIdx.x;
+        uint4 mk4; mk4.x = m0.x; mk4.y = m0.y; mk4.z = k0.x; mk4.w = k0.y;
+        x_mk[base + my_rank] = mk4;
+        x_src[base + my_rank] = (unsigned char)threadIdx.x;
         __syncthreads();
-        slot = blockIdx.x * 256 + perm[threadIdx.x];
-    }
+        mk4 = x_mk[threadIdx.x];
+        slot = blockIdx.x * 256 + x_src[threadIdx.x];
+        m.x = mk4.x; m.y = mk4.y; ki.x = mk4.z; ki.y = mk4.w;
 #endif
+    }
     bool active_after = false, want_unit = false;
     uint32_t c_samp = 0, c_seg2 = 0, c_hit2 = 0; unsigned long long c_draws = 0;
-    if (slot < B.P) {
-        uint2 m = B.ld2(SF_MA, slot);
-        if (m.y & F_ACTIVE) {
+    {
+        if (m.y & F_ACTIVE) {   // (a thread beyond the pool got meta = 0 from the prologue)
             const uint32_t NONE = 0xFFFFFFFFu;
-            Ray ray; ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
-            const uint2 ki = B.ld2(SF_HIT_KI, slot);
-            Rng g; g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, slot)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
-            int b_inner = (int)((m.y >> 8) & 0xFFu);
             const bool first = (m.y & F_FIRST) != 0;
-            const int depth_inner = cam.max_depth - 1;
+#ifdef ZR_SHADE_TOUCH
+            // experiment, off: first and last line of the record object_rec() will read, requested with the state rows (cfg3 +1.3 %:
+            // the record's own read costs less than the extra requests).  The loads
+            // are invisible to the compiler's wait counting, which is safe: memory returns in order, so every wait it inserts for
+            // a younger load covers them; the register they write stays reserved until the hit branch has waited for the ray.
+            uint32_t touch = 0;
+            if (ki.x == ZR_PRIM_TRIANGLE) {
+                const double* q = sc.tri_s + (size_t)ki.y * 20;
+                asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:156" : "=&v"(touch) : "v"(q) : "memory");
+            } else if (ki.x == ZR_PRIM_SPHERE) {
+                const double* q = sc.spheres + (size_t)ki.y * 4;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(touch) : "v"(q) : "memory");
+            }
+#endif
+            // every row this segment reads, requested in one go (a row of a slot is always addressable; what a path does not
+            // need is not requested: beta before the second hit, the unit id is 8 bytes)
+            Ray ray; ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
+            Rng g; g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, slot)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
+            const uint2 mb_now = B.ld2(SF_MB, slot);
+            const double t_hit = B.ld(SF_HIT_T, slot);
             // after the first hit L = 0 and beta = 1 (camera.hpp:930): both stay implicit (two flag bits) until something else is
             // stored, which saves their 48 bytes written and read back per path; the values used are the same (0 + x, 1 * x)
+            V3 beta_now = mk(1, 1, 1);
+            if (!first && !(m.y & F_BONE)) beta_now = B.ld3(SF_BETA, slot);
+            V3 att0_now = mk(0, 0, 0);
+            if (!first && ki.x == NONE) att0_now = B.ld3(SF_ATT0, slot);   // a miss ends the path: its sample is att0 * (L + beta * background)
+            int b_inner = (int)((m.y >> 8) & 0xFFu);
+            const int depth_inner = cam.max_depth - 1;
             auto load_L = [&]() { return (m.y & F_LZERO) ? mk(0, 0, 0) : B.ld3(SF_L, slot); };
-            auto load_beta = [&]() { return (m.y & F_BONE) ? mk(1, 1, 1) : B.ld3(SF_BETA, slot); };
+            auto load_beta = [&]() { return beta_now; };
             uint32_t keep_lzero = m.y & F_LZERO;
             // the split passes count segments and hits here (SHADE sees every segment exactly once), so that their EXTEND can be
             // the uninstrumented build; the replay's first segment is the beauty pass's, found again: not counted
@@ -501,22 +572,25 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                         V3 scol = load_L() + load_beta() * bg;
                         const double luma = 0.2126 * len(scol);                  // camera.hpp:499-503
                         if (luma > 2.0) scol = scol * (2.0 / luma);
-                        contrib = B.ld3(SF_ATT0, slot) * scol;
+                        contrib = att0_now * scol;
                     } else {
-                        contrib = first ? bg : B.ld3(SF_ATT0, slot) * (load_L() + load_beta() * bg);  // camera.hpp:520 / 941,1000
+                        contrib = first ? bg : att0_now * (load_L() + load_beta() * bg);  // camera.hpp:520 / 941,1000
                     }
                     ended = true;
                 }
             } else {
-                const double t = B.ld(SF_HIT_T, slot);
+                const double t = t_hit;
                 V3 em, att; Ray nr; bool sc_ok;
                 uint32_t cls_now = 0;
                 {
                     Rec rec;
+#ifdef ZR_SHADE_TOUCH
+                    asm volatile("" ::"v"(touch), "v"(ray.o.x), "v"(ray.d.z));   // the ray is here, so the touches (older) have returned
+#endif
                     object_rec(sc, ki.x, ki.y, ray, t, rec);
                     em = emitted(sc, rec);
                     if (MODE == 2 && first) {   // the stream continues where the beauty path of this sample stopped
-                        const uint2 ke = B.kend[B.ld2(SF_MB, slot).x];
+                        const uint2 ke = B.kend[mb_now.x];
                         g.k = ke.x; g.bounce = ke.y;
                     }
                     sc_ok = scatter(sc, ray, rec, att, nr, g);
@@ -532,7 +606,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     if (!sc_ok || depth_inner <= 0) { ended = true; if (MODE == 2) no_output = true; }
                     else {
                         B.st3(SF_ATT0, slot, att);   // L = 0, beta = 1: implicit (F_LZERO | F_BONE below)
-                        if (MODE == 2) { uint2 mb = B.ld2(SF_MB, slot); mb.y = cls_now; B.st2(SF_MB, slot, mb); }
+                        if (MODE == 2) { uint2 mb = mb_now; mb.y = cls_now; B.st2(SF_MB, slot, mb); }
                         b_inner = 0;
                     }
                 } else {      // body of ray_color's loop, camera.hpp:944-983
@@ -578,7 +652,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 V3 rad = contrib;
                 if (has_add) rad = add_now + rad;
                 else if (MODE != 2 && !first && (m.y & F_L0)) rad = B.ld3(SF_SUM, slot) + rad;
-                const uint2 mb = B.ld2(SF_MB, slot);
+                const uint2 mb = mb_now;
                 const uint32_t unit = mb.x;
                 if (MODE != 2 || !no_output) {
                     double* pp = B.samples + (size_t)unit * 3;
@@ -731,16 +805,18 @@ size_t stream_ctl_words() { return 16 + 32 * ST_SHARDS; }
 uint32_t stream_overflow_levels(uint32_t stack_demand) { return stack_demand > ST_LDS_STACK ? stack_demand - ST_LDS_STACK : 1u; }
 size_t stream_overflow_bytes(int blocks, uint32_t levels) { return (size_t)blocks * levels * 64 * sizeof(SEntry); }
 
+// number of EXTEND waves that are resident at once (the persistent grid), a multiple of the workgroup's ST_EXT_GROUP
 int stream_extend_blocks() {
-    int dev = 0, cus = 256, per_cu = 16;
+    int dev = 0, cus = 256, per_cu = 2;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipDeviceProp_t p;
         if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     }
     int lean = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false, 2>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lean, stream_extend<false, 0>, 64, 0) == hipSuccess && lean > per_cu) per_cu = lean;
-    return cus * per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_extend<false, 2>, 64 * ST_EXT_GROUP, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&lean, stream_extend<false, 0>, 64 * ST_EXT_GROUP, 0) == hipSuccess && lean > per_cu) per_cu = lean;
+    if (std::getenv("ZR_COMMIT_STATS")) std::fprintf(stderr, "[zr] EXTEND workgroups per CU: %d (lean build %d) x %d waves\n", per_cu, lean, ST_EXT_GROUP);
+    return cus * per_cu * ST_EXT_GROUP;
 }
 
 // layout of the slot pool inside one allocation; returns bytes needed
@@ -756,9 +832,11 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
 
 template <bool COUNT>
 static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, uint32_t ovf_levels, int blocks, unsigned long long* gctr, int level, hipStream_t st) {
-    if (level >= 2) hipLaunchKernelGGL((stream_extend<COUNT, 2>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
-    else if (level == 1) hipLaunchKernelGGL((stream_extend<COUNT, 1>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
-    else hipLaunchKernelGGL((stream_extend<COUNT, 0>), dim3(blocks), dim3(64), 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    // `blocks` counts waves (at most stream_extend_blocks(), a multiple of ST_EXT_GROUP: the overflow slabs are sized for that many)
+    const dim3 grid((blocks + ST_EXT_GROUP - 1) / ST_EXT_GROUP), group(64 * ST_EXT_GROUP);
+    if (level >= 2) hipLaunchKernelGGL((stream_extend<COUNT, 2>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else if (level == 1) hipLaunchKernelGGL((stream_extend<COUNT, 1>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else hipLaunchKernelGGL((stream_extend<COUNT, 0>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
 }
 
 // The slot pool can be split into K sub-pools that run a fraction of a round apart on K HIP streams, so that one
