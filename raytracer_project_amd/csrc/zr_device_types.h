@@ -33,12 +33,8 @@ static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 // lane and instruction, and a random record costs the fabric one request whatever its size.
 //   q[0..2] = lower x, y, z planes, q[3..5] = upper; byte c of each word belongs to child c.
 //   ref[c]: ZR_REF_EMPTY, an inner node's index, or ZR_REF_LEAF | kind << 28 | (count - 1) << 24 | first primitive.
-//   An inner reference with ZR_REF_TOP set indexes DScene::top instead: the nodes of the first levels under the root, which
-//   EXTEND keeps in LDS (a visit there costs the vector memory pipe nothing).
 #define ZR_REF_LEAF 0x80000000u
 #define ZR_REF_EMPTY 0xFFFFFFFFu
-#define ZR_REF_TOP 0x40000000u
-#define ZR_TOP_MAX 84u /* 4 + 16 + 64: three full levels under the root */
 struct alignas(64) NodeQ {
     float origin[3];
     float scale[3];
@@ -80,8 +76,6 @@ struct DScene {
     uint32_t n_mats;
     uint32_t mat_kinds;  // bit k set: a material of kind k exists (SHADE sorts by kind only when more than one does)
     NodeF root;          // variant 2: the root of the 4-wide tree
-    const NodeQ* top;    // variant 2: copies of the first levels' nodes (references to them carry ZR_REF_TOP), n_top <= ZR_TOP_MAX
-    uint32_t n_top, pad2_;
 };
 
 struct DCamera {

@@ -154,7 +154,7 @@ struct zr_scene {
     // device
     bool committed = false;
     DevBuf<zr::NodePair> d_nodes;
-    DevBuf<zr::NodeQ> d_quads, d_top;
+    DevBuf<zr::NodeQ> d_quads;
     bool quad_ok = true;          // leaf references fit the EXTEND kernel's 32-bit stack entries
     DevBuf<double> d_spheres, d_tri_v, d_tri_s, d_cubes, d_pcubes;
     DevBuf<uint32_t> d_sphere_mat, d_cube_mat, d_pcube_mat;
@@ -651,7 +651,6 @@ struct Flattener {
         }
         quad_depth = (int)levels.size() - 1;
         quant_ok = quant_ok_a.load(); n_kept_closed = kept_closed_a.load();
-        build_top((int)env_double("ZR_TOP_LEVELS", 3));
     }
     // Worst-case number of entries the EXTEND kernel's per-lane stack holds for this 4-wide tree: visiting a node whose
     // nk children are all hit pushes nk - 1 of them and descends into the nearest (any child can be the nearest), or
@@ -662,29 +661,9 @@ struct Flattener {
         for (int k = 0; k < 4; k++) if (refs[k] != ZR_REF_EMPTY) nk++;
         for (int k = 0; k < 4; k++) {
             if (refs[k] == ZR_REF_EMPTY || (refs[k] & ZR_REF_LEAF)) continue;
-            best = std::max(best, demand_of((refs[k] & ZR_REF_TOP) ? top[refs[k] & ~ZR_REF_TOP].ref : quads[refs[k]].ref));
+            best = std::max(best, demand_of(quads[refs[k]].ref));
         }
         return std::max(nk, nk ? nk - 1 + best : 0u);
-    }
-    // The nodes of the first `levels_wanted` levels under the root, copied out in breadth-first order (at most ZR_TOP_MAX):
-    // the traversal kernel keeps them in LDS.  Every reference to one of them — they only occur in the root and in these
-    // nodes themselves — becomes ZR_REF_TOP | position; `quads` keeps the originals, which nothing reaches any more.
-    std::vector<zr::NodeQ> top;
-    void build_top(int levels_wanted) {
-        top.clear();
-        std::vector<uint32_t*> frontier;   // reference words that may point at the next level
-        for (int k = 0; k < 4; k++) frontier.push_back(&root.ref[k]);
-        top.reserve(ZR_TOP_MAX);           // the pointers below point into `top`: no reallocation
-        for (int l = 0; l < levels_wanted && !frontier.empty(); l++) {
-            std::vector<uint32_t*> next;
-            for (uint32_t* r : frontier) {
-                if (*r == ZR_REF_EMPTY || (*r & ZR_REF_LEAF) || top.size() >= ZR_TOP_MAX) continue;
-                top.push_back(quads[*r]);
-                *r = ZR_REF_TOP | (uint32_t)(top.size() - 1);
-                for (int k = 0; k < 4; k++) next.push_back(&top.back().ref[k]);
-            }
-            frontier.swap(next);
-        }
     }
     uint32_t stack_demand() const { return demand_of(root.ref); }
     void run() {
@@ -1048,7 +1027,6 @@ int zr_scene_commit(zr_scene* s) {
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
-    if ((rc = s->d_top.upload(fl.top))) return rc;
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
     s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
                  fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24);
@@ -1096,7 +1074,6 @@ int zr_scene_commit(zr_scene* s) {
     d.mat_kinds = 0;
     for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
     d.root = fl.root;
-    d.top = s->d_top.p; d.n_top = (uint32_t)fl.top.size(); d.pad2_ = 0;
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         bool plain_media = true;   // media whose boundary is an unwrapped sphere or cube
         for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) plain_media = false;

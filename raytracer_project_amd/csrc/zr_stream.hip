@@ -49,7 +49,7 @@ namespace zr {
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
-#define ST_LDS_STACK 11
+#define ST_LDS_STACK 12
 #endif
 
 enum { F_FIRST = 1u << 16, F_ACTIVE = 1u << 17, F_L0 = 1u << 18,
@@ -147,36 +147,22 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
 // Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
 // host sizes the slab from the exact worst-case demand of the committed tree (Flattener::stack_demand), so no push can
 // leave it.
-// Workgroup = ST_EXT_GROUP waves that share nothing but the LDS copy of the tree's first levels (DScene::top, at most
-// ZR_TOP_MAX nodes, 80-byte stride so that lanes reading different nodes spread over the banks): every wave keeps its own
-// stack slice, ray chunks and state machine, and after the barrier that publishes the copy no wave waits for another.
-// Why: the kernel's time follows the number of divergent 16-byte requests its lanes put through the vector memory pipe
-// (one more 4-byte request per node visit, of bytes already being fetched: +10.6 %, profiles/r2_experiments_ab.txt) —
-// and the first levels take 2 of a ray's 4-5 node visits.
+// ST_EXT_GROUP waves form a workgroup; they share nothing (own stack slice, ray chunks and state machine).  1 is the measured
+// best: groups of 8 sharing an LDS copy of the tree's first three levels (84 nodes) were tried in round 2 — the copy's reads
+// and the extra branch in the node step cost more than the requests they saved (cfg3 3.31 -> 3.60 ms per launch, cfg5 -3 %
+// against +1 % for the grouping alone): profiles/r2_experiments_ab.txt.
 #ifndef ST_EXT_GROUP
-#define ST_EXT_GROUP 8
+#define ST_EXT_GROUP 1
 #endif
-#define ST_TOP_STRIDE 20  /* dwords */
 template <bool COUNT, int LEVEL>
 __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
                                                                   uint32_t ovf_levels, unsigned long long* __restrict__ gctr) {
     __shared__ SEntry lstack[ST_EXT_GROUP * ST_LDS_STACK * 64];
-#ifndef ZR_EXT_NO_TOP
-    __shared__ __attribute__((aligned(16))) uint32_t ltop[ZR_TOP_MAX * ST_TOP_STRIDE];
-#endif
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = blockIdx.x * ST_EXT_GROUP + (threadIdx.x >> 6);
     const int lbase = (int)(threadIdx.x >> 6) * ST_LDS_STACK * 64 + lane;   // this lane's column of this wave's stack slice
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     SEntry* gstack = overflow + (size_t)wave_id * ovf_levels * 64 + lane;
-#ifndef ZR_EXT_NO_TOP
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.top);
-        const uint32_t n = (sc.n_top < ZR_TOP_MAX ? sc.n_top : ZR_TOP_MAX) * 16u;
-        for (uint32_t i = threadIdx.x; i < n; i += 64 * ST_EXT_GROUP) ltop[(i >> 4) * ST_TOP_STRIDE + (i & 15u)] = src[i];
-        __syncthreads();
-    }
-#endif
     const double INF = __builtin_huge_val();
     const float INFf = __builtin_huge_valf();
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -349,18 +335,8 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEV
             if (st == X_NODE) {
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
-                uint4 w0, w1, w2, ref;
-#ifndef ZR_EXT_NO_TOP
-                if (cur & ZR_REF_TOP) {   // one of the first levels' nodes: from the workgroup's LDS copy
-                    const uint4* lq = reinterpret_cast<const uint4*>(&ltop[(cur & 0xFFFFu) * ST_TOP_STRIDE]);
-                    w0 = lq[0]; w1 = lq[1]; w2 = lq[2]; ref = lq[3];
-                } else
-#endif
-                {
-                    // (a build without the LDS copy reads such a node from the copy's source)
-                    const uint4* nq = reinterpret_cast<const uint4*>((cur & ZR_REF_TOP) ? sc.top + (cur & 0xFFFFu) : sc.quads + cur);
-                    w0 = nq[0]; w1 = nq[1]; w2 = nq[2]; ref = nq[3];
-                }
+                const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
+                const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
                 // t = fmaf(q, a, b): a = scale * id, b = the node origin's parametric distance (the lower planes' b moved
                 // by -2^-15 a, the upper planes' by +2^-15 a: towards "earlier" resp. "later" whatever the sign of id)
                 const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
