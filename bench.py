@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+RANDOM_RECORD_PEAK_G = 60.0   # G dependent random records/s beyond L2, measured on MI355X by scripts/dev/randread.hip (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -225,6 +226,11 @@ def main():
                     continue
         node_util = ctr.node_lanes / max(1, ctr.node_execs) / 64.0
         leaf_util = ctr.leaf_lanes / max(1, ctr.leaf_execs) / 64.0
+        # every lane-step of the walk fetches ONE randomly placed record (a 64-B node, a 72-B triangle, a 32-B sphere ...): the
+        # rate at which the chip serves dependent random records is what the kernel runs against (scripts/dev/randread.hip, same
+        # occupancy: ~60 G records/s from arrays beyond the L2s whatever the record size up to 128 B, ~206 G/s L2-resident)
+        records = (ctr.node_lanes + ctr.triangles_tested + ctr.spheres_tested + ctr.cubes_tested + ctr.media_tested) if variant == 2 else None
+        rec_rate = (records / launches_per_step) / (k_ms * 1e-3) * 1e-9 if (records and k_ms > 0) else None
         out = {
             "metric": "Msamples/sec (rays·bounces)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -246,8 +252,16 @@ def main():
                          "frac_traffic": round(traffic / (k_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 5) if (traffic and k_ms > 0) else None,
                          "achieved_layout": round(achieved_layout, 2) if achieved_layout else None,
                          "frac_layout": round(achieved_layout / HBM_PEAK_GBS, 5) if achieved_layout else None,
-                         "bound_note": (f"not HBM-bound: the BVH walk is limited by VALU issue at {100 * node_util:.0f} % (NODE) / {100 * leaf_util:.0f} % (LEAF) "
-                                        "lane utilisation plus random 64-B node requests that mostly hit L2 / Infinity Cache (tree + vertices fit its 256 MiB); "
+                         "random_records_per_launch": int(records / launches_per_step) if records else None,
+                         "random_record_rate_G_per_s": round(rec_rate, 2) if rec_rate else None,
+                         "random_record_peak_G_per_s": RANDOM_RECORD_PEAK_G,
+                         "frac_random_records": round(rec_rate / RANDOM_RECORD_PEAK_G, 4) if rec_rate else None,
+                         "bound_note": ("not bound by HBM bytes: every lane-step of the walk fetches one randomly placed record (node / triangle / sphere), "
+                                        f"and the kernel moves them at random_record_rate_G_per_s against the ~{RANDOM_RECORD_PEAK_G:.0f} G records/s this chip serves "
+                                        "dependent random records from arrays beyond its L2s at the same occupancy (scripts/dev/randread.hip; ~206 G/s L2-resident; "
+                                        "about half the walk's requests hit L2).  Round-2 experiments (profiles/r2_experiments_ab.txt): more ready lanes per "
+                                        f"iteration (now {100 * node_util:.0f} % NODE / {100 * leaf_util:.0f} % LEAF), merged node+leaf iterations, an LDS copy of the tree top, "
+                                        "prefetch touches and 128-byte-aligned triangles all left the time where it is or raised it; one more request per node visit costs 10 %.  "
                                         "frac is the algorithmic work rate SURVEY 8(d) defines, frac_traffic the counter bytes over the same time"),
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "launches_timed": len(launches),
                          "kernel_ms_per_step": round(sum(launches) / max(1, args.steps), 3),
