@@ -233,7 +233,7 @@ __device__ __forceinline__ bool pcube_t(const double* q, const Ray& r, double tm
 __device__ inline bool bare_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, double& t) {
     if (kind == ZR_PRIM_SPHERE) return sphere_t(sc.spheres + (size_t)idx * 4, r, tmin, tmax, t);
     if (kind == ZR_PRIM_CUBE) return cube_t(sc.cubes + (size_t)idx * 6, r, tmin, tmax, t);
-    return triangle_t(sc.tri_v + (size_t)idx * 9, r, tmin, tmax, t);
+    return triangle_t(sc.tri_v + (size_t)idx * ZR_TRI_STRIDE, r, tmin, tmax, t);
 }
 
 // constant_medium.hpp:39-77, distance only

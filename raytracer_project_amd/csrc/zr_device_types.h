@@ -6,6 +6,9 @@
 #define ZR_KIND_WRAPPED 4u /* leaf kind: object with a wrapper chain (index into DScene::wrapped) */
 #define ZR_KIND_PCUBE 5u   /* leaf kind: a "placed" cube — cube -> [rotate_y] -> translate, the way every cube of the reference's scenes enters the
                               world (scene_management.hpp:132-139): the two wrapper parameters travel with the cube (DScene::pcubes) */
+#ifndef ZR_TRI_STRIDE
+#define ZR_TRI_STRIDE 9    /* doubles between two records of DScene::tri_v (9 are used) */
+#endif
 #define ZR_STACK_DEPTH 48  /* builder guarantees tree depth <= ZR_STACK_DEPTH */
 #define ZR_MAX_CHAIN 8
 

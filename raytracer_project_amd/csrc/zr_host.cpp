@@ -331,7 +331,7 @@ struct Flattener {
         sphere_mat[di] = mat != kKeepMaterial ? mat : s.sphere_mat[idx];
     }
     void put_triangle_raw(size_t di, const double* v, const double* nn, uint32_t mat, bool force_front) {
-        std::memcpy(&tri_v[di * 9], v, 72);
+        std::memcpy(&tri_v[di * ZR_TRI_STRIDE], v, 72);
         double* t = &tri_s[di * 20];
         std::memcpy(t, v, 72); std::memcpy(t + 9, nn, 72);
         uint64_t mbits = mat, fbits = force_front ? 1u : 0u;
@@ -706,7 +706,7 @@ struct Flattener {
         n_sph = cnt[ZR_PRIM_SPHERE]; n_tri = cnt[ZR_PRIM_TRIANGLE]; n_cube = cnt[ZR_PRIM_CUBE]; n_pcube = cnt[ZR_KIND_PCUBE];
         n_media = cnt[ZR_PRIM_MEDIUM]; n_wrapped = cnt[ZR_KIND_WRAPPED];
         spheres.allocate((n_sph + x_sph) * 4); sphere_mat.allocate(n_sph + x_sph);
-        tri_v.allocate((n_tri + x_tri) * 9); tri_s.allocate((n_tri + x_tri) * 20);
+        tri_v.allocate((n_tri + x_tri) * ZR_TRI_STRIDE); tri_s.allocate((n_tri + x_tri) * 20);
         cubes.allocate((n_cube + x_cube) * 6); cube_mat.allocate(n_cube + x_cube);
         pcubes.allocate(n_pcube * 12); pcube_mat.allocate(n_pcube);
         media.allocate(n_media + x_media); wrapped.allocate(n_wrapped);

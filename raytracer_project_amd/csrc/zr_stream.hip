@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEV
                 if (is_leaf && lkind == ZR_PRIM_TRIANGLE) {
                     double t;
                     if (COUNT) c_tri++;
-                    if (triangle_t(sc.tri_v + (size_t)prim * 9, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
+                    if (triangle_t(sc.tri_v + (size_t)prim * ZR_TRI_STRIDE, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
             } else if (do_sph) {
