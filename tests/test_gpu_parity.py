@@ -7,6 +7,8 @@ Bar (BASELINE.json north_star): radiance within 1e-4 relative per channel on ide
 pixel indexing, segment counts and RNG-draw counts bit-exact.  The device computes in FP64 like the reference
 but with FMA contraction, so individual values differ from the reference in the last bits (~1e-15 relative);
 REL_TOL below is the north-star bound, not a fudge factor."""
+import os
+
 import numpy as np
 import pytest
 
@@ -377,6 +379,54 @@ def test_smallest_slot_pool_renders_the_same_image(built, monkeypatch):
         finally:
             c.close()
     assert np.array_equal(frames[0], frames[1])
+
+
+def test_unit_order_does_not_change_the_image(built, monkeypatch):
+    """Work units are handed out bottom-up (the frame's drain is as long as the paths started last, and the top rows are where
+    the one-segment sky samples are); top-down must give the same bits, counters included."""
+    from raytracer_project_amd import capi
+    ds = demo_scene("mix0")
+    cam = ds.camera.copy()
+    cam.samples_per_pixel = 32
+    frames, segs = [], []
+    c = capi.Context(0)
+    try:
+        sc = capi.Scene(c, ds.desc)
+        for order in ("1", "0"):
+            monkeypatch.setenv("ZR_STREAM_BOTTOM_UP", order)
+            frames.append(sc.render(cam, ds.env, ds.seed, None, count=True))
+            k = c.counters()
+            segs.append((k.segments, k.rng_draws, k.primary_samples))
+        sc.close()
+    finally:
+        c.close()
+    assert np.array_equal(frames[0], frames[1]) and segs[0] == segs[1]
+
+
+def test_bench_line_contract(built):
+    """bench.py on the reference's own CPU-sized case: one JSON line with the driver's keys, the roofline object (incl. the
+    random-record rate the traversal kernel runs against) and a CPU baseline whose port reproduces the reference's counts."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg1", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["dtype"] == "f64" and "workload" in d["config"]
+    rf = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "frac_layout", "random_record_rate_G_per_s",
+                "frac_random_records", "bound_note", "kernel", "kernel_ms", "launches_timed"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "stream_extend"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0 and rf["launches_timed"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
+    if cb["kind"] == "reference":
+        assert cb["port"]["value"] > 0 and cb["port_matches_reference"] is True
 
 
 def test_dropin_cpp_api_renders(ctx):
