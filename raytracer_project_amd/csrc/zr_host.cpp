@@ -298,13 +298,14 @@ struct Flattener {
     const zr::BuildResult& br;
     zr::RawArray<zr::NodePair> pairs;
     std::vector<zr::NodeQ> quads;
-    std::vector<uint32_t> leaf_first;  // per build node: device index of a leaf's first primitive
+    zr::RawArray<uint32_t> leaf_first; // per build node: device index of a leaf's first primitive
     int quad_depth = 0;
     zr::RawArray<double> spheres, tri_v, tri_s, cubes, pcubes;
     zr::RawArray<uint32_t> sphere_mat, cube_mat, pcube_mat;
     zr::RawArray<zr::DMedium> media;
     zr::RawArray<zr::DWrapped> wrapped;
     size_t n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0;   // filled sizes (the arrays are sized exactly)
+    std::function<void()> after_primitives;   // called by run() once spheres / triangles / cubes / media / wrapped are complete
     const std::vector<uint8_t>* baked = nullptr;   // per object: 0 as is, 1 baked triangle, 2 material-only chain, 3 baked sphere, 4 placed cube
     size_t n_baked = 0;
     int threads = 1;
@@ -448,17 +449,51 @@ struct Flattener {
 
     // ---- the serial walk: pair numbers in pre-order, leaf ranges per kind, in the order a depth-first emit would visit them ----
     std::vector<int32_t> inner;        // inner build nodes, position = pair index
-    std::vector<uint32_t> pair_of;     // per build node
+    zr::RawArray<uint32_t> pair_of;    // per build node
     std::vector<int32_t> leaves;       // leaf build nodes in emit order
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // leaf objects per kind
-    void walk(int32_t id) {
-        pair_of[id] = (uint32_t)inner.size(); inner.push_back(id);
-        const int32_t ch[2] = {br.nodes[id].left, br.nodes[id].right};
-        for (int k = 0; k < 2; k++) {
-            const zr::BuildNode& c = br.nodes[ch[k]];
-            if (c.count) { leaf_first[ch[k]] = cnt[c.kind & 7]; cnt[c.kind & 7] += c.count; leaves.push_back(ch[k]); }
-            else walk(ch[k]);
+    // Pair index of every inner node, first-primitive index of every leaf, and the two lists, in the order of a depth-first walk
+    // (node, left subtree, right subtree).  The builder numbers nodes so that this order IS ascending node id (left = id + 1,
+    // right = id + 2 x the left subtree's references: zr_bvh.cpp), with unused ids in between — fresh pages, all zero, which no
+    // real node is (a leaf has count > 0, an inner node left = id + 1 > 0) — so the walk is two passes of prefix sums over the
+    // id range, every thread on its own slice, instead of a serial recursion over two million nodes.
+    void index_nodes() {
+        const size_t N = br.nodes.size();
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), N / 65536 + 1));
+        struct Tally { size_t inner = 0, leaves = 0; uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+        std::vector<Tally> tally((size_t)T);
+        auto is_inner = [&](size_t id) { const zr::BuildNode& n = br.nodes[id]; return n.count == 0 && n.left == (int32_t)id + 1; };
+        auto pass = [&](auto&& body) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back([&body, t, T, N]() { body(t, N * (size_t)t / (size_t)T, N * (size_t)(t + 1) / (size_t)T); });
+            body(0, (size_t)0, N / (size_t)T);
+            for (auto& x : th) x.join();
+        };
+        pass([&](int t, size_t a, size_t b) {
+            Tally y;
+            for (size_t id = a; id < b; id++) {
+                const zr::BuildNode& n = br.nodes[id];
+                if (n.count) { y.leaves++; y.cnt[n.kind & 7] += n.count; } else if (is_inner(id)) y.inner++;
+            }
+            tally[(size_t)t] = y;
+        });
+        Tally run;
+        std::vector<Tally> start((size_t)T);
+        for (int t = 0; t < T; t++) {
+            start[(size_t)t] = run;
+            run.inner += tally[(size_t)t].inner; run.leaves += tally[(size_t)t].leaves;
+            for (int k = 0; k < 8; k++) run.cnt[k] += tally[(size_t)t].cnt[k];
         }
+        inner.resize(run.inner); leaves.resize(run.leaves);
+        for (int k = 0; k < 8; k++) cnt[k] = run.cnt[k];
+        pass([&](int t, size_t a, size_t b) {
+            Tally y = start[(size_t)t];
+            for (size_t id = a; id < b; id++) {
+                const zr::BuildNode& n = br.nodes[id];
+                if (n.count) { leaf_first[id] = y.cnt[n.kind & 7]; y.cnt[n.kind & 7] += n.count; leaves[y.leaves++] = (int32_t)id; }
+                else if (is_inner(id)) { pair_of[id] = (uint32_t)y.inner; inner[y.inner++] = (int32_t)id; }
+            }
+        });
     }
     void fill_pair(uint32_t p, int32_t node_id) {
         const int32_t ch[2] = {br.nodes[node_id].left, br.nodes[node_id].right};
@@ -676,7 +711,7 @@ struct Flattener {
             if (const char* e = std::getenv("ZR_BVH_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
             threads = (int)std::max(1u, std::min(32u, hw));
         }
-        leaf_first.assign(br.nodes.size(), 0);
+        leaf_first.allocate(br.nodes.size());   // fresh pages: zero
         if (baked) for (uint8_t b : *baked) if (b) n_baked++;
         if (br.nodes.empty()) {
             pairs.allocate(1); empty_child(0, 0); empty_child(0, 1);
@@ -684,17 +719,18 @@ struct Flattener {
             return;
         }
         // 1. indices
-        pair_of.assign(br.nodes.size(), 0);
+        pair_of.allocate(br.nodes.size());
         if (br.nodes[0].count) { leaf_first[0] = 0; cnt[br.nodes[0].kind & 7] = br.nodes[0].count; leaves.push_back(0); }   // the whole world fits one leaf
-        else { inner.reserve(br.nodes.size() / 2 + 1); leaves.reserve(br.nodes.size() / 2 + 1); walk(0); }
-        ph("index walk");
+        else index_nodes();
+        ph("index pass");
         // 2. array sizes: the leaf ranges, then the primitives inside media and wrapper chains
         size_t x_sph = 0, x_tri = 0, x_cube = 0, x_media = 0;
         auto count_inner = [&](uint32_t type, uint32_t idx, auto&& self) -> void {
             if (type == ZR_PRIM_SPHERE) x_sph++; else if (type == ZR_PRIM_TRIANGLE) x_tri++; else if (type == ZR_PRIM_CUBE) x_cube++;
             else { x_media++; self(s.media[idx].boundary_type, s.media[idx].boundary_index, self); }
         };
-        for (int32_t lf : leaves) {
+        const bool any_compound = cnt[ZR_PRIM_MEDIUM] + cnt[ZR_KIND_WRAPPED] != 0;   // (a million-leaf scan for nothing otherwise)
+        if (any_compound) for (int32_t lf : leaves) {
             const zr::BuildNode& n = br.nodes[lf];
             if (n.kind != ZR_PRIM_MEDIUM && n.kind != ZR_KIND_WRAPPED) continue;
             for (uint32_t k = 0; k < n.count; k++) {
@@ -720,7 +756,7 @@ struct Flattener {
         });
         ph("primitive records");
         // media and wrapped objects, with what they contain: serial, in emit order
-        for (int32_t lf : leaves) {
+        if (any_compound) for (int32_t lf : leaves) {
             const zr::BuildNode& n = br.nodes[lf];
             if (n.kind != ZR_PRIM_MEDIUM && n.kind != ZR_KIND_WRAPPED) continue;
             for (uint32_t k = 0; k < n.count; k++) {
@@ -736,6 +772,7 @@ struct Flattener {
             }
         }
         ph("media / wrapped");
+        if (after_primitives) after_primitives();   // the primitive arrays are final: their upload can run beside the rest
         // 4. pair records: all threads
         if (inner.empty()) { pairs.allocate(1); fill_leaf_root(); }
         else {
@@ -1019,27 +1056,52 @@ int zr_scene_commit(zr_scene* s) {
     phase("binned-SAH build");
     if (br.max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "BVH depth %d exceeds the traversal stack", br.max_depth);
 
-    Flattener fl{*s, objs, br};
+    // the flattener lives on the heap: it is handed, with everything else that is large, to a thread that frees it (below)
+    std::shared_ptr<Flattener> flp(new Flattener{*s, objs, br});
+    Flattener& fl = *flp;
     fl.baked = &baked;
     fl.open_ratio = env_double("ZR_BVH_OPEN_RATIO", 1.25);
+    // the primitive arrays (a quarter of a gigabyte for a million triangles) go to the device while the host still plans and
+    // numbers the 4-wide nodes: a thread of its own, joined before the node arrays follow
+    int up_rc = ZR_OK;
+    std::string up_err;
+    std::thread uploader;
+    const int device = s->ctx ? s->ctx->device : 0;
+    fl.after_primitives = [&]() {
+        uploader = std::thread([&, device]() {
+            auto go = [&]() -> int {
+                HIP_OK(hipSetDevice(device));
+                int r;
+                if ((r = s->d_spheres.upload(fl.spheres))) return r;
+                if ((r = s->d_sphere_mat.upload(fl.sphere_mat))) return r;
+                if ((r = s->d_tri_v.upload(fl.tri_v))) return r;
+                if ((r = s->d_tri_s.upload(fl.tri_s))) return r;
+                if ((r = s->d_cubes.upload(fl.cubes))) return r;
+                if ((r = s->d_cube_mat.upload(fl.cube_mat))) return r;
+                if ((r = s->d_pcubes.upload(fl.pcubes))) return r;
+                if ((r = s->d_pcube_mat.upload(fl.pcube_mat))) return r;
+                if ((r = s->d_media.upload(fl.media))) return r;
+                if ((r = s->d_wrapped.upload(fl.wrapped))) return r;
+                return ZR_OK;
+            };
+            up_rc = go();
+            if (up_rc != ZR_OK) up_err = g_err;   // the error text is per thread
+        });
+    };
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // no path leaves the thread running
     fl.run();
     phase("flatten + quantise");
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
+    if (uploader.joinable()) uploader.join();
+    else if (fl.after_primitives) {   // a world without nodes returned from run() before the hook: upload the (empty) arrays here
+        fl.after_primitives(); if (uploader.joinable()) uploader.join();
+    }
+    if (up_rc != ZR_OK) return fail(up_rc, "%s", up_err.c_str());
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
     s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
                  fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24);
-    if ((rc = s->d_spheres.upload(fl.spheres))) return rc;
-    if ((rc = s->d_sphere_mat.upload(fl.sphere_mat))) return rc;
-    if ((rc = s->d_tri_v.upload(fl.tri_v))) return rc;
-    if ((rc = s->d_tri_s.upload(fl.tri_s))) return rc;
-    if ((rc = s->d_cubes.upload(fl.cubes))) return rc;
-    if ((rc = s->d_cube_mat.upload(fl.cube_mat))) return rc;
-    if ((rc = s->d_pcubes.upload(fl.pcubes))) return rc;
-    if ((rc = s->d_pcube_mat.upload(fl.pcube_mat))) return rc;
-    if ((rc = s->d_media.upload(fl.media))) return rc;
-    if ((rc = s->d_wrapped.upload(fl.wrapped))) return rc;
     if ((rc = s->d_ops.upload(s->ops.data(), s->ops.size()))) return rc;
     {
         // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
@@ -1095,13 +1157,11 @@ int zr_scene_commit(zr_scene* s) {
     }
     phase("upload");
     {   // unmapping half a gigabyte of staging arrays takes tens of milliseconds: not on the caller's clock
-        struct Trash { zr::BuildResult br; zr::RawArray<zr::NodePair> pairs; zr::RawArray<double> a, b, c, d, e; zr::RawArray<uint32_t> f, g, h; std::vector<zr::NodeQ> quads;
-                       zr::RawArray<uint32_t> qs, qi; std::vector<zr::BuildBox> boxes; std::vector<zr_object> objs; };
+        struct Trash { std::shared_ptr<Flattener> fl; zr::BuildResult br; std::vector<zr::BuildBox> boxes; std::vector<zr_object> objs;
+                       std::vector<uint32_t> kinds; std::vector<uint8_t> baked; };
         auto t = std::make_shared<Trash>();
-        t->br = std::move(br); t->pairs = std::move(fl.pairs); t->a = std::move(fl.spheres); t->b = std::move(fl.tri_v); t->c = std::move(fl.tri_s); t->d = std::move(fl.cubes);
-        t->e = std::move(fl.pcubes); t->f = std::move(fl.sphere_mat); t->g = std::move(fl.cube_mat); t->h = std::move(fl.pcube_mat); t->quads = std::move(fl.quads);
-        t->qs = std::move(fl.q_size); t->qi = std::move(fl.q_index); t->boxes = std::move(boxes); t->objs = std::move(objs);
-        fl.plan.clear();   // never touched beyond the planned nodes' pages: cheap
+        fl.after_primitives = nullptr;   // (it captures locals of this call)
+        t->fl = std::move(flp); t->br = std::move(br); t->boxes = std::move(boxes); t->objs = std::move(objs); t->kinds = std::move(kinds); t->baked = std::move(baked);
         try { std::thread([t]() mutable { t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
     }
     phase("release");
