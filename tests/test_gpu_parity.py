@@ -403,6 +403,32 @@ def test_unit_order_does_not_change_the_image(built, monkeypatch):
     assert np.array_equal(frames[0], frames[1]) and segs[0] == segs[1]
 
 
+@pytest.mark.parametrize("var,values", [("ZR_STREAM_POOLS", ("1", "2", "3")), ("ZR_EXTEND_LEVEL", ("-1", "2"))])
+def test_pipeline_shape_does_not_change_the_image(var, values, built, monkeypatch):
+    """Sub-pools on separate HIP streams (the default for a rank's share of a sharded frame) and the build of the traversal
+    kernel chosen for a scene (lean / cubes-and-media / everything) are scheduling and code-size choices: same bits, same counters."""
+    from raytracer_project_amd import capi
+    for name in ("mix0", "cfg5" if var == "ZR_EXTEND_LEVEL" else "mix1"):
+        ds = demo_scene(name)
+        cam = ds.camera.copy()
+        cam.samples_per_pixel = min(cam.samples_per_pixel, 48)
+        frames, ctrs = [], []
+        for v in values:
+            monkeypatch.setenv(var, v)
+            monkeypatch.setenv("ZR_STREAM_SLOTS", "262144")   # a pool small enough to be split
+            c = capi.Context(0)
+            try:
+                sc = capi.Scene(c, ds.desc)
+                frames.append(sc.render(cam, ds.env, ds.seed, None, count=True))
+                k = c.counters()
+                ctrs.append((k.segments, k.rng_draws, k.primary_samples, k.hits))
+                sc.close()
+            finally:
+                c.close()
+        for f, k in zip(frames[1:], ctrs[1:]):
+            assert np.array_equal(frames[0], f) and ctrs[0] == k, (name, var)
+
+
 def test_bench_line_contract(built):
     """bench.py on the reference's own CPU-sized case: one JSON line with the driver's keys, the roofline object (incl. the
     random-record rate the traversal kernel runs against) and a CPU baseline whose port reproduces the reference's counts."""
