@@ -14,7 +14,9 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -310,11 +312,58 @@ struct Flattener {
     size_t n_baked = 0;
     int threads = 1;
 
+    // Workers that live as long as run(): the level-synchronous passes below call parallel_for some forty times, and starting
+    // thirty-one threads each time cost more than the passes' own work (plan + numbering 34 ms -> see profiles/r2_commit_stats.txt).
+    struct Pool {
+        std::vector<std::thread> th;
+        std::mutex m;
+        std::condition_variable go, done;
+        std::function<void(int)> job;
+        uint64_t gen = 0;
+        int parts = 0, pending = 0;
+        bool stop = false;
+        explicit Pool(int workers) {
+            for (int w = 1; w <= workers; w++)
+                th.emplace_back([this, w]() {
+                    uint64_t seen = 0;
+                    for (;;) {
+                        std::function<void(int)> f;
+                        {
+                            std::unique_lock<std::mutex> lk(m);
+                            go.wait(lk, [&] { return stop || gen != seen; });
+                            if (stop) return;
+                            seen = gen;
+                            if (w >= parts) continue;
+                            f = job;
+                        }
+                        f(w);
+                        { std::lock_guard<std::mutex> lk(m); if (--pending == 0) done.notify_one(); }
+                    }
+                });
+        }
+        ~Pool() {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            go.notify_all();
+            for (auto& x : th) x.join();
+        }
+        void run(int n_parts, const std::function<void(int)>& f) {   // f(0 .. n_parts - 1), part 0 on the caller
+            { std::lock_guard<std::mutex> lk(m); job = f; parts = n_parts; pending = n_parts - 1; gen++; }
+            go.notify_all();
+            f(0);
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return pending == 0; });
+        }
+    };
+    mutable std::unique_ptr<Pool> pool;
     template <class F>
     void parallel_for(size_t n, size_t grain, F&& fn) const {   // fn(begin, end) over [0, n) split evenly
         int T = threads;
         if (n < 2 * grain) T = 1; else T = (int)std::min<size_t>((size_t)T, n / grain);
         if (T <= 1) { fn((size_t)0, n); return; }
+        if (pool && T <= (int)pool->th.size() + 1) {
+            pool->run(T, [&fn, n, T](int t) { fn(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); });
+            return;
+        }
         std::vector<std::thread> th;
         for (int t = 1; t < T; t++) th.emplace_back([&fn, n, t, T]() { fn(n * t / T, n * (t + 1) / T); });
         fn((size_t)0, n / T);
@@ -711,6 +760,8 @@ struct Flattener {
             if (const char* e = std::getenv("ZR_BVH_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
             threads = (int)std::max(1u, std::min(32u, hw));
         }
+        if (threads > 1 && br.nodes.size() > 65536) pool.reset(new Pool(threads - 1));
+        struct Unpool { std::unique_ptr<Pool>& p; ~Unpool() { p.reset(); } } unpool{pool};   // the workers end with run()
         leaf_first.allocate(br.nodes.size());   // fresh pages: zero
         if (baked) for (uint8_t b : *baked) if (b) n_baked++;
         if (br.nodes.empty()) {
