@@ -186,6 +186,7 @@ struct flat_scene {
     std::vector<zr_medium> media;
     std::vector<zr_xform_op> ops;
     std::vector<zr_object> objects;
+    std::vector<zr_group> groups;
     std::vector<zr_material> materials;
     std::vector<zr_texture> textures;
     std::vector<unsigned char> texels;
@@ -201,6 +202,7 @@ struct flat_scene {
         d.materials = materials.data(); d.n_materials = materials.size();
         d.textures = textures.data(); d.n_textures = textures.size();
         d.texels = texels.data(); d.texel_bytes = texels.size();
+        d.groups = groups.data(); d.n_groups = groups.size();
         return d;
     }
 };
@@ -249,12 +251,69 @@ public:
 
     void unsupported(const char* what) { fs.warnings.push_back(std::string("unsupported hittable skipped: ") + what); }
 
+    // TWO-LEVEL BVH.  A mesh (model, bvh_node of triangles) that sits under wrappers is what the reference shares between
+    // instances (the same shared_ptr in several translate / rotate_* / scale / material_instance objects): its triangles are
+    // flattened ONCE, in their own space, as a zr_group, and every placement becomes one ZR_PRIM_GROUP object carrying the
+    // wrapper chain.  `children` flattens the child's parts.  A child that turns out not to be bare triangles, or that is placed
+    // only once (finish()), is flattened the plain way: one entry per triangle, each with the chain.
+    template <class F>
+    void emit_run(const void* identity, F&& children) {
+        const char* e_ = std::getenv("ZR_GROUPS");
+        const bool off = e_ && *e_ == '0';   // ZR_GROUPS=0: always one entry per triangle
+        if (off || chain.empty() || in_boundary || in_run) { children(); return; }
+        auto it = run_ids.find(identity);
+        if (it == run_ids.end()) {
+            std::vector<zr_xform_op> outer; outer.swap(chain);
+            const size_t first = fs.tri_mat.size();
+            in_run = true; run_ok = true;
+            children();
+            in_run = false; chain.swap(outer);
+            const size_t n = fs.tri_mat.size() - first;
+            if (!run_ok || n == 0) {   // not a run of bare triangles: forget what was captured and flatten it in place
+                fs.tri_v.resize(first * 9); fs.tri_n.resize(first * 9); fs.tri_mat.resize(first);
+                run_ids[identity] = 0xFFFFFFFFu;
+                children();
+                return;
+            }
+            zr_group g{}; g.first_triangle = (uint32_t)first; g.triangle_count = (uint32_t)n;
+            fs.groups.push_back(g);
+            it = run_ids.emplace(identity, (uint32_t)fs.groups.size() - 1).first;
+        }
+        if (it->second == 0xFFFFFFFFu) { children(); return; }
+        emit(ZR_PRIM_GROUP, it->second);
+    }
+    // call once, after the world has been flattened and before flat_scene::desc(): groups placed a single time gain nothing from
+    // a tree of their own — their placement is replaced by its triangles (each under the placement's chain) unless
+    // ZR_GROUP_ALWAYS is set
+    void finish() {
+        if (fs.groups.empty()) return;
+        const char* always = std::getenv("ZR_GROUP_ALWAYS");
+        std::vector<uint32_t> uses(fs.groups.size(), 0);
+        for (const zr_object& o : fs.objects) if (o.type == ZR_PRIM_GROUP) uses[o.index]++;
+        std::vector<uint32_t> new_id(fs.groups.size(), 0xFFFFFFFFu);
+        std::vector<zr_group> kept;
+        for (size_t g = 0; g < fs.groups.size(); g++)
+            if (uses[g] > 1 || (uses[g] == 1 && always && *always && *always != '0')) { new_id[g] = (uint32_t)kept.size(); kept.push_back(fs.groups[g]); }
+        std::vector<zr_object> out;
+        out.reserve(fs.objects.size());
+        for (const zr_object& o : fs.objects) {
+            if (o.type != ZR_PRIM_GROUP) { out.push_back(o); continue; }
+            if (new_id[o.index] != 0xFFFFFFFFu) { zr_object q = o; q.index = new_id[o.index]; out.push_back(q); continue; }
+            const zr_group& g = fs.groups[o.index];
+            for (uint32_t k = 0; k < g.triangle_count; k++) { zr_object q = o; q.type = ZR_PRIM_TRIANGLE; q.index = g.first_triangle + k; out.push_back(q); }
+        }
+        fs.objects.swap(out);
+        fs.groups.swap(kept);
+    }
+
 private:
     std::vector<zr_xform_op> chain;  // wrappers currently open, outermost first
     size_t boundary_base = 0;
     bool in_boundary = false;
     zr_object captured{};            // the boundary primitive of the medium being flattened
     bool captured_ok = false;
+    bool in_run = false, run_ok = true;   // capturing a group's triangles (emit_run)
+    std::unordered_map<const void*, uint32_t> run_ids;   // child object -> its group (0xFFFFFFFF: not a run)
     std::unordered_map<const material*, uint32_t> mat_ids;
     std::unordered_map<const texture*, uint32_t> tex_ids;
 public:
@@ -269,6 +328,10 @@ private:
     void emit(uint32_t type, uint32_t index) {
         zr_object o{};
         o.type = type; o.index = index;
+        if (in_run) {   // a group's own triangle: not a world-list entry; anything else (or a wrapper inside) ends the capture
+            if (type != ZR_PRIM_TRIANGLE || !chain.empty()) run_ok = false;
+            return;
+        }
         if (in_boundary) {
             o.chain_count = (uint32_t)(chain.size() - boundary_base);
             o.chain_first = copy_chain(boundary_base, chain.size());
@@ -784,7 +847,7 @@ public:
     bvh_node(hittable_list l) : list(std::move(l)) { zenith::consume_draws(zenith::bvh_ctor_draws(list.objects.size())); }
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return list.bounding_box(); }
-    void flatten(zenith::scene_builder& b) const override { list.flatten(b); }
+    void flatten(zenith::scene_builder& b) const override { b.emit_run(this, [&] { list.flatten(b); }); }
 private:
     hittable_list list;
 };
@@ -876,7 +939,7 @@ public:
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void set_material(std::shared_ptr<material> m) { mat = m; }   // like the reference's: does not re-material existing triangles
-    void flatten(zenith::scene_builder& b) const override { for (const auto& t : tris) t->flatten(b); }
+    void flatten(zenith::scene_builder& b) const override { b.emit_run(this, [&] { for (const auto& t : tris) t->flatten(b); }); }
     size_t triangle_count() const { return tris.size(); }
 private:
     std::vector<shared_ptr<triangle>> tris;
@@ -1008,6 +1071,7 @@ inline shared_ptr<device_object> device_commit(shared_ptr<device_object>& cache,
     d->ctx = ctx;
     scene_builder b(d->fs);
     flatten(b);
+    b.finish();
     d->mats = b.mat_ptrs;
     for (const auto& w : d->fs.warnings) std::cerr << "[zenith] " << w << "\n";
     d->sc = zr_scene_create(ctx);
@@ -1125,6 +1189,7 @@ public:
         render_accumulator.assign((size_t)image_width * image_height, color(0, 0, 0));  // the reference only fills (camera.hpp:420)
         zenith::flat_scene fs; zenith::scene_builder b(fs);
         world.flatten(b);
+        b.finish();
         zr_env zenv = zenith::to_zr_env(env, b);
         for (const auto& w : fs.warnings) std::cerr << "[zenith] " << w << "\n";
         zr_ctx* ctx = zenith::thread_context(device);

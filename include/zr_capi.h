@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ZR_ABI_VERSION 1
+#define ZR_ABI_VERSION 2
 
 enum {
     ZR_OK = 0,
@@ -44,7 +44,10 @@ enum {
     ZR_PRIM_SPHERE = 0,   /* sphere            /root/reference/sphere.hpp:5-89 */
     ZR_PRIM_TRIANGLE = 1, /* triangle          /root/reference/triangle.hpp:5-110 */
     ZR_PRIM_CUBE = 2,     /* cube              /root/reference/cube.hpp:7-143 */
-    ZR_PRIM_MEDIUM = 3    /* constant_medium   /root/reference/constant_medium.hpp:24-87 */
+    ZR_PRIM_MEDIUM = 3,   /* constant_medium   /root/reference/constant_medium.hpp:24-87 */
+    ZR_PRIM_GROUP = 6     /* a run of triangles (zr_group) placed as ONE object: what a wrapper around a mesh is in the reference
+                             (translate / rotate_* / scale / material_instance holding a model or a bvh_node, scene_management.hpp:
+                             112-117): the run is stored and built once however many objects name it (two-level BVH) */
 };
 
 /* instance wrappers (applied outermost first to the ray, innermost first to the hit record) */
@@ -70,6 +73,14 @@ typedef struct zr_object {
     uint32_t chain_first; /* first wrapper op (outermost) in the op array */
     uint32_t chain_count; /* number of wrapper ops, 0 = bare primitive */
 } zr_object;
+
+/* triangles [first_triangle, first_triangle + triangle_count) of the triangle arrays, in their own (object) space; they are not
+ * world-list entries themselves.  A zr_object of type ZR_PRIM_GROUP with index = position in the group array places the run
+ * under that object's wrapper chain; several objects may place the same group. */
+typedef struct zr_group {
+    uint32_t first_triangle;
+    uint32_t triangle_count;
+} zr_group;
 
 /* constant_medium(boundary, density, tex|color): boundary is a sphere or cube entry that is not
  * itself part of the world list; `mat` is the id of a ZR_MAT_ISOTROPIC material. */
@@ -198,6 +209,7 @@ typedef struct zr_scene_desc {
     const zr_material* materials; uint64_t n_materials;
     const zr_texture* textures; uint64_t n_textures;
     const void* texels;         uint64_t texel_bytes;
+    const zr_group* groups;     uint64_t n_groups;   /* ABI 2 */
 } zr_scene_desc;
 
 typedef struct zr_ctx zr_ctx;
@@ -223,6 +235,9 @@ int zr_scene_set_xform_ops(zr_scene*, const zr_xform_op*, size_t n);
 /* the world list.  If never called, every sphere/triangle/cube/medium that is not a medium boundary
  * is a bare top-level object. */
 int zr_scene_set_objects(zr_scene*, const zr_object*, size_t n);
+/* runs of triangles that ZR_PRIM_GROUP objects place (needs an explicit world list: the implicit one would also list the
+ * runs' triangles as bare objects) */
+int zr_scene_set_groups(zr_scene*, const zr_group*, size_t n);
 int zr_scene_set_materials(zr_scene*, const zr_material*, size_t n);
 int zr_scene_set_textures(zr_scene*, const zr_texture*, size_t n, const void* texel_blob, size_t texel_bytes);
 /* all of the above in one call */

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     zr_build_refdemo(s);
     zenith::flat_scene fs; zenith::scene_builder b(fs);
     s.world.flatten(b);
+    b.finish();
     zr_env env = zenith::to_zr_env(s.env, b);
     zr_scene_desc d = fs.desc();
     if (std::string(argv[1]) == "stats") {

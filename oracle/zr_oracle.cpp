@@ -566,7 +566,14 @@ struct Scene {
 
     void prepare() {
         if (d.n_objects) {
-            objects.assign(d.objects, d.objects + d.n_objects);
+            // a ZR_PRIM_GROUP entry (a run of triangles placed as one object: the device's two-level BVH) is, for this checker, its
+            // triangles one by one under the entry's wrapper chain — the same arithmetic, no sharing needed here
+            for (uint64_t k = 0; k < d.n_objects; k++) {
+                const zr_object& o = d.objects[k];
+                if (o.type != ZR_PRIM_GROUP) { objects.push_back(o); continue; }
+                const zr_group& g = d.groups[o.index];
+                for (uint32_t q = 0; q < g.triangle_count; q++) objects.push_back({ZR_PRIM_TRIANGLE, g.first_triangle + q, o.chain_first, o.chain_count});
+            }
         } else {
             std::vector<char> sb(d.n_spheres, 0), cb(d.n_cubes, 0);
             for (uint64_t k = 0; k < d.n_media; k++) {

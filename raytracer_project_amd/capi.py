@@ -145,7 +145,8 @@ class SceneDesc(C.Structure):
                 ("objects", C.c_void_p), ("n_objects", C.c_uint64),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint64),
                 ("textures", C.c_void_p), ("n_textures", C.c_uint64),
-                ("texels", C.c_void_p), ("texel_bytes", C.c_uint64)]
+                ("texels", C.c_void_p), ("texel_bytes", C.c_uint64),
+                ("groups", C.c_void_p), ("n_groups", C.c_uint64)]
 
 
 _lib = None
@@ -155,7 +156,7 @@ _scenes = None
 CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
-    "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_materials", "zr_scene_set_textures",
+    "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_groups", "zr_scene_set_materials", "zr_scene_set_textures",
     "zr_scene_set_all", "zr_scene_set_all_borrowed", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_gather_frame", "zr_comm_destroy",
 ]

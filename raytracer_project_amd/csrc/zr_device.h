@@ -299,12 +299,89 @@ __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, c
     return bare_t(sc, kind, idx, r, tmin, tmax, t);
 }
 
+__device__ __forceinline__ void slab_constants(double d, double o, double& id, double& o_id);
+// ---- two-level BVH: a run of triangles placed under a wrapper chain (ZR_KIND_INSTANCE) -----------------------------------
+// closest triangle of a run's subtree (sibling-pair records whose leaves are triangles) for a ray already mapped into the
+// run's space; the walk of closest_hit below, on a stack of its own.  n_boxes / n_tris: tests made (instrumented builds).
+__device__ inline bool run_hit(const DScene& sc, uint32_t root, const Ray& r, double tmin, double tmax, double& t_out, uint32_t& tri_out,
+                               uint32_t& n_boxes, uint32_t& n_tris) {
+    double idx_, idy_, idz_, ox_, oy_, oz_;
+    slab_constants(r.d.x, r.o.x, idx_, ox_); slab_constants(r.d.y, r.o.y, idy_, oy_); slab_constants(r.d.z, r.o.z, idz_, oz_);
+    double tbest = tmax;
+    bool found = false;
+    uint32_t stk[ZR_STACK_DEPTH];
+    int sp = 0;
+    uint32_t cur = root;
+    for (;;) {
+        const NodePair* np = sc.nodes + cur;
+        const float4 q0 = reinterpret_cast<const float4*>(np)[0];
+        const float4 q1 = reinterpret_cast<const float4*>(np)[1];
+        const float4 q2 = reinterpret_cast<const float4*>(np)[2];
+        const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+        n_boxes += 2;
+        double tn[2], tf[2];
+        {
+            double a0 = fma((double)q0.x, idx_, -ox_), a1 = fma((double)q1.z, idx_, -ox_);
+            double b0 = fma((double)q0.y, idy_, -oy_), b1 = fma((double)q1.w, idy_, -oy_);
+            double c0 = fma((double)q0.z, idz_, -oz_), c1 = fma((double)q2.x, idz_, -oz_);
+            tn[0] = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), tmin));
+            tf[0] = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
+        }
+        {
+            double a0 = fma((double)q0.w, idx_, -ox_), a1 = fma((double)q2.y, idx_, -ox_);
+            double b0 = fma((double)q1.x, idy_, -oy_), b1 = fma((double)q2.z, idy_, -oy_);
+            double c0 = fma((double)q1.y, idz_, -oz_), c1 = fma((double)q2.w, idz_, -oz_);
+            tn[1] = fmax(fmax(fmin(a0, a1), fmin(b0, b1)), fmax(fmin(c0, c1), tmin));
+            tf[1] = fmin(fmin(fmax(a0, a1), fmax(b0, b1)), fmin(fmax(c0, c1), tbest));
+        }
+        const bool h[2] = {tn[0] <= tf[0], tn[1] <= tf[1]};
+        const uint32_t c[2] = {q3.x, q3.y};
+        const uint32_t m[2] = {q3.z, q3.w};
+        uint32_t next = 0xFFFFFFFFu, defer = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (!h[s]) continue;
+            if (m[s] != 0) {
+                const uint32_t cnt = m[s] & 0xFFFFu;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    double t;
+                    n_tris++;
+                    if (triangle_t(sc.tri_v + (size_t)(c[s] + k) * ZR_TRI_STRIDE, r, tmin, tbest, t)) { tbest = t; tri_out = c[s] + k; found = true; }
+                }
+            } else {
+                if (next == 0xFFFFFFFFu) next = c[s]; else defer = c[s];
+            }
+        }
+        if (defer != 0xFFFFFFFFu) {
+            if (tn[1] < tn[0]) { uint32_t x = next; next = defer; defer = x; }
+            if (sp < ZR_STACK_DEPTH) stk[sp++] = defer;
+        }
+        if (next == 0xFFFFFFFFu) {
+            if (sp == 0) break;
+            next = stk[--sp];
+        }
+        cur = next;
+    }
+    t_out = tbest;
+    return found;
+}
+// the instance's test: the wrappers' ray maps outermost first (what translate / rotate_* / scale ::hit do before calling the
+// child), then the child's own tree; t is the same in both spaces
+__device__ inline bool instance_t(const DScene& sc, uint32_t inst, const Ray& r, double tmin, double tmax, double& t, uint32_t& tri,
+                                  uint32_t& n_boxes, uint32_t& n_tris) {
+    const DInstance in = sc.insts[inst];
+    const Ray lr = chain_ray(sc, in.chain_first, in.chain_count, r);
+    return run_hit(sc, in.root, lr, tmin, tmax, t, tri, n_boxes, n_tris);
+}
+
 // material id a hit on leaf object (kind, idx) will carry: the primitive's own, or that of the outermost material_instance
 // of its wrapper chain (material_instance.hpp:19-21; object_rec applies the chain inside-out, so the outermost one wins)
 __device__ inline uint32_t object_material(const DScene& sc, uint32_t kind, uint32_t idx) {
     uint32_t type = kind, index = idx, mat_override = 0xFFFFFFFEu;
-    if (kind == ZR_KIND_WRAPPED) {
-        const DWrapped w = sc.wrapped[idx];
+    if (kind == ZR_KIND_WRAPPED || (kind & 0xFFu) == ZR_KIND_INSTANCE) {
+        DWrapped w;
+        if (kind == ZR_KIND_WRAPPED) w = sc.wrapped[idx];
+        else { const DInstance in = sc.insts[kind >> 8]; w.type = ZR_PRIM_TRIANGLE; w.index = idx; w.chain_first = in.chain_first; w.chain_count = in.chain_count; }
         type = w.type; index = w.index;
         for (uint32_t k = 0; k < w.chain_count; k++)
             if (sc.ops[w.chain_first + k].kind == ZR_OP_MATERIAL) { mat_override = sc.ops[w.chain_first + k].mat; break; }
@@ -418,8 +495,11 @@ __device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx,
         apply_op_rec(op, r.d, rec);
         return;
     }
-    if (kind != ZR_KIND_WRAPPED) { bare_rec(sc, kind, idx, r, t, rec, full); return; }
-    const DWrapped w = sc.wrapped[idx];
+    const bool placed_run = (kind & 0xFFu) == ZR_KIND_INSTANCE;   // a triangle of a run: the record of a triangle under the instance's chain
+    if (kind != ZR_KIND_WRAPPED && !placed_run) { bare_rec(sc, kind, idx, r, t, rec, full); return; }
+    DWrapped w;
+    if (placed_run) { const DInstance in = sc.insts[kind >> 8]; w.type = ZR_PRIM_TRIANGLE; w.index = idx; w.chain_first = in.chain_first; w.chain_count = in.chain_count; }
+    else w = sc.wrapped[idx];
     Ray lr = chain_ray(sc, w.chain_first, w.chain_count, r);
     bare_rec(sc, w.type, w.index, lr, t, rec, true);  // a material_instance in the chain may replace the material
     for (int k = (int)w.chain_count - 1; k >= 0; k--) {
@@ -495,6 +575,11 @@ __device__ inline bool closest_hit(const DScene& sc, const Ray& r, double tmin, 
                         if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[c[s] + k].type;
                         if (kk == ZR_PRIM_SPHERE) ctr.sph++; else if (kk == ZR_PRIM_TRIANGLE) ctr.tri++; else if (kk == ZR_PRIM_CUBE || kk == ZR_KIND_PCUBE) ctr.cube++; else ctr.med++;
                     }
+                    if (kind == ZR_KIND_INSTANCE) {
+                        uint32_t tri = 0, nb = 0, nt = 0;
+                        if (instance_t(sc, c[s] + k, r, tmin, tbest, t, tri, nb, nt)) { tbest = t; kbest = ZR_KIND_INSTANCE | ((c[s] + k) << 8); ibest = tri; }
+                        if (COUNT) { ctr.nodes += nb; ctr.tri += nt; ctr.med--; }   // (the line above counted the instance itself as "other")
+                    } else
                     if (object_t(sc, kind, c[s] + k, r, tmin, tbest, g, t)) { tbest = t; kbest = kind; ibest = c[s] + k; }
                 }
             } else {

@@ -6,6 +6,8 @@
 #define ZR_KIND_WRAPPED 4u /* leaf kind: object with a wrapper chain (index into DScene::wrapped) */
 #define ZR_KIND_PCUBE 5u   /* leaf kind: a "placed" cube — cube -> [rotate_y] -> translate, the way every cube of the reference's scenes enters the
                               world (scene_management.hpp:132-139): the two wrapper parameters travel with the cube (DScene::pcubes) */
+#define ZR_KIND_INSTANCE 6u /* leaf kind (= ZR_PRIM_GROUP): a run of triangles with a pair-BVH of its own, placed under a wrapper chain (DScene::insts).
+                              A hit on one is reported as kind = ZR_KIND_INSTANCE | instance << 8, index = the triangle. */
 #ifndef ZR_TRI_STRIDE
 #define ZR_TRI_STRIDE 9    /* doubles between two records of DScene::tri_v (9 are used) */
 #endif
@@ -56,6 +58,7 @@ struct DMedium {
     double neg_inv_density;
 };
 struct DWrapped { uint32_t type, index, chain_first, chain_count; };
+struct DInstance { uint32_t chain_first, chain_count, root /* pair index of the run's subtree in DScene::nodes */, pad_; };
 
 struct DScene {
     const NodePair* nodes;
@@ -72,6 +75,7 @@ struct DScene {
     const uint32_t* pcube_mat;
     const DMedium* media;
     const DWrapped* wrapped;
+    const DInstance* insts;
     const zr_xform_op* ops;
     const zr_material* mats;
     const zr_texture* texs;

@@ -148,6 +148,7 @@ struct zr_scene {
     HostArray<zr_xform_op> ops;
     HostArray<zr_object> objects;
     bool objects_set = false;
+    std::vector<zr_group> groups;   // runs of triangles that ZR_PRIM_GROUP objects place (small: copied)
     bool borrowed = false;        // the geometry arrays are the caller's (released after the commit)
     bool released = false;        // ... and have been released: the scene cannot be committed again without new input
     std::vector<zr_material> materials;
@@ -162,6 +163,7 @@ struct zr_scene {
     DevBuf<uint32_t> d_sphere_mat, d_cube_mat, d_pcube_mat;
     DevBuf<zr::DMedium> d_media;
     DevBuf<zr::DWrapped> d_wrapped;
+    DevBuf<zr::DInstance> d_insts;
     DevBuf<zr_xform_op> d_ops;
     DevBuf<zr_material> d_mats;
     DevBuf<zr_texture> d_texs;
@@ -177,8 +179,10 @@ namespace {
 // ---- bounding boxes of world-list entries, following the reference's constructors --------------------
 struct Boxer {
     const zr_scene& s;
+    const std::vector<zr::BuildBox>* group_box = nullptr;   // per zr_group: the box of its triangles in their own space
     zr::BuildBox prim(uint32_t type, uint32_t idx) const {
         zr::BuildBox b;
+        if (type == ZR_PRIM_GROUP) return (*group_box)[idx];
         if (type == ZR_PRIM_SPHERE) {  // sphere.hpp:12-14 (raw radius argument)
             const double* q = &s.spheres[(size_t)idx * 4];
             for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(q[k] - q[3], q[k] + q[3]); b.hi[k] = std::fmax(q[k] - q[3], q[k] + q[3]); }
@@ -260,6 +264,7 @@ int validate(const zr_scene& s, const std::vector<zr_object>& objs) {
             case ZR_PRIM_TRIANGLE: return idx < s.tri_mat.size();
             case ZR_PRIM_CUBE: return idx < s.cube_mat.size();
             case ZR_PRIM_MEDIUM: return idx < s.media.size();
+            case ZR_PRIM_GROUP: return idx < s.groups.size();
             default: return false;
         }
     };
@@ -268,6 +273,9 @@ int validate(const zr_scene& s, const std::vector<zr_object>& objs) {
         if (!prim_ok(m.boundary_type, m.boundary_index) || !chain_ok(m.chain_first, m.chain_count) || !mat_ok(m.mat))
             return fail(ZR_E_INVALID, "medium references out of range (or wrapper chain longer than %d)", ZR_MAX_CHAIN);
     }
+    for (const zr_group& g : s.groups)
+        if (g.triangle_count == 0 || (size_t)g.first_triangle + g.triangle_count > s.tri_mat.size()) return fail(ZR_E_INVALID, "group of triangles out of range (or empty)");
+    if (!s.groups.empty() && !s.objects_set) return fail(ZR_E_INVALID, "groups need an explicit world list (zr_scene_set_objects)");
     for (const zr_object& o : objs)
         if (!prim_ok(o.type, o.index) || !chain_ok(o.chain_first, o.chain_count))
             return fail(ZR_E_INVALID, "world-list entry references out of range (or wrapper chain longer than %d)", ZR_MAX_CHAIN);
@@ -306,6 +314,9 @@ struct Flattener {
     zr::RawArray<uint32_t> sphere_mat, cube_mat, pcube_mat;
     zr::RawArray<zr::DMedium> media;
     zr::RawArray<zr::DWrapped> wrapped;
+    zr::RawArray<zr::DInstance> insts;
+    const std::vector<zr::BuildResult>* runs = nullptr;   // per zr_group: the tree over its triangles (object space), built by the caller
+    std::vector<uint32_t> run_root;                       // per group: pair index of its subtree's root
     size_t n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0;   // filled sizes (the arrays are sized exactly)
     std::function<void()> after_primitives;   // called by run() once spheres / triangles / cubes / media / wrapped are complete
     const std::vector<uint8_t>* baked = nullptr;   // per object: 0 as is, 1 baked triangle, 2 material-only chain, 3 baked sphere, 4 placed cube
@@ -467,7 +478,8 @@ struct Flattener {
     void put_leaf_object(uint32_t oi, size_t di) {
         const zr_object& o = objs[oi];
         const uint8_t bk = baked ? (*baked)[oi] : 0;
-        if (bk == 1) put_baked_triangle(di, o);
+        if (o.type == ZR_PRIM_GROUP) { zr::DInstance in{}; in.chain_first = o.chain_first; in.chain_count = o.chain_count; in.root = run_root[o.index]; insts[di] = in; }
+        else if (bk == 1) put_baked_triangle(di, o);
         else if (bk == 3) put_baked_sphere(di, o);
         else if (bk == 4) put_pcube(di, o);
         else {
@@ -486,6 +498,46 @@ struct Flattener {
             case ZR_PRIM_CUBE: put_cube(n_cube, idx, kKeepMaterial); return (uint32_t)n_cube++;
             default: { const size_t di = n_media++; put_medium(di, idx); return (uint32_t)di; }
         }
+    }
+    // A group's subtree: its triangles, unbaked, behind the leaf ranges of the triangle arrays in the order its leaves name them, and
+    // its sibling-pair records from pair index `base` on, numbered in pre-order (= ascending build-node id, as in index_nodes).
+    // Returns the number of pair records written (at least one: a run that fits one leaf gets a pair with an empty second child).
+    uint32_t emit_run(uint32_t g, uint32_t base) {
+        const zr::BuildResult& rb = (*runs)[g];
+        const zr_group& grp = s.groups[g];
+        auto leaf_tris = [&](const zr::BuildNode& n) {   // -> first device index
+            const uint32_t first = (uint32_t)n_tri;
+            for (uint32_t k = 0; k < n.count; k++) { put_triangle(n_tri, grp.first_triangle + rb.order[n.first + k]); n_tri++; }
+            return first;
+        };
+        if (rb.nodes[0].count) {
+            const zr::BuildNode& n = rb.nodes[0];
+            for (int k = 0; k < 3; k++) { pairs[base].lo[0][k] = f_down(n.box.lo[k]); pairs[base].hi[0][k] = f_up(n.box.hi[k]); }
+            pairs[base].child[0] = leaf_tris(n); pairs[base].meta[0] = ((ZR_PRIM_TRIANGLE + 1u) << 16) | n.count;
+            empty_child(base, 1);
+            return 1;
+        }
+        std::vector<uint32_t> ids;   // inner nodes, ascending id = pre-order
+        for (size_t id = 0; id < rb.nodes.size(); id++) { const zr::BuildNode& n = rb.nodes[id]; if (n.count == 0 && n.left == (int32_t)id + 1) ids.push_back((uint32_t)id); }
+        auto pair_index = [&](uint32_t id) { return base + (uint32_t)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
+        for (size_t p = 0; p < ids.size(); p++) {
+            const zr::BuildNode& n = rb.nodes[ids[p]];
+            const int32_t ch[2] = {n.left, n.right};
+            for (int slot = 0; slot < 2; slot++) {
+                const zr::BuildNode& c = rb.nodes[ch[slot]];
+                zr::NodePair& pr = pairs[base + p];
+                for (int k = 0; k < 3; k++) { pr.lo[slot][k] = f_down(c.box.lo[k]); pr.hi[slot][k] = f_up(c.box.hi[k]); }
+                if (c.count) { pr.child[slot] = leaf_tris(c); pr.meta[slot] = ((ZR_PRIM_TRIANGLE + 1u) << 16) | c.count; }
+                else { pr.child[slot] = pair_index((uint32_t)ch[slot]); pr.meta[slot] = 0; }
+            }
+        }
+        return (uint32_t)ids.size();
+    }
+    static uint32_t run_pairs(const zr::BuildResult& rb) {   // pair records emit_run will write
+        if (rb.nodes.empty() || rb.nodes[0].count) return 1;
+        uint32_t n = 0;
+        for (size_t id = 0; id < rb.nodes.size(); id++) { const zr::BuildNode& q = rb.nodes[id]; if (q.count == 0 && q.left == (int32_t)id + 1) n++; }
+        return n;
     }
     void put_medium(size_t di, uint32_t idx) {
         const zr_medium& m = s.media[idx];
@@ -792,6 +844,16 @@ struct Flattener {
         }
         n_sph = cnt[ZR_PRIM_SPHERE]; n_tri = cnt[ZR_PRIM_TRIANGLE]; n_cube = cnt[ZR_PRIM_CUBE]; n_pcube = cnt[ZR_KIND_PCUBE];
         n_media = cnt[ZR_PRIM_MEDIUM]; n_wrapped = cnt[ZR_KIND_WRAPPED];
+        size_t run_pair_total = 0;
+        if (runs) for (size_t g = 0; g < runs->size(); g++) { x_tri += s.groups[g].triangle_count; run_pair_total += run_pairs((*runs)[g]); }
+        insts.allocate(cnt[ZR_KIND_INSTANCE]);
+        const size_t main_pairs = std::max<size_t>(1, inner.size());
+        pairs.allocate(main_pairs + run_pair_total);
+        if (runs) {   // where each group's subtree will start (the records follow the world's own)
+            run_root.resize(runs->size());
+            size_t at = main_pairs;
+            for (size_t g = 0; g < runs->size(); g++) { run_root[g] = (uint32_t)at; at += run_pairs((*runs)[g]); }
+        }
         spheres.allocate((n_sph + x_sph) * 4); sphere_mat.allocate(n_sph + x_sph);
         tri_v.allocate((n_tri + x_tri) * ZR_TRI_STRIDE); tri_s.allocate((n_tri + x_tri) * 20);
         cubes.allocate((n_cube + x_cube) * 6); cube_mat.allocate(n_cube + x_cube);
@@ -805,6 +867,7 @@ struct Flattener {
                 for (uint32_t k = 0; k < n.count; k++) put_leaf_object(br.order[n.first + k], (size_t)leaf_first[leaves[i]] + k);
             }
         });
+        if (runs) for (size_t g = 0; g < runs->size(); g++) emit_run((uint32_t)g, run_root[g]);   // serial: runs are shared, hence few
         ph("primitive records");
         // media and wrapped objects, with what they contain: serial, in emit order
         if (any_compound) for (int32_t lf : leaves) {
@@ -825,9 +888,8 @@ struct Flattener {
         ph("media / wrapped");
         if (after_primitives) after_primitives();   // the primitive arrays are final: their upload can run beside the rest
         // 4. pair records: all threads
-        if (inner.empty()) { pairs.allocate(1); fill_leaf_root(); }
+        if (inner.empty()) fill_leaf_root();
         else {
-            pairs.allocate(inner.size());
             parallel_for(inner.size(), 4096, [&](size_t a, size_t b) { for (size_t p = a; p < b; p++) fill_pair((uint32_t)p, inner[p]); });
         }
         ph("pair records");
@@ -961,6 +1023,12 @@ int zr_scene_set_objects(zr_scene* s, const zr_object* o, size_t n) {
     s->objects.copy(o, n); s->objects_set = n > 0;
     return ZR_OK;
 }
+int zr_scene_set_groups(zr_scene* s, const zr_group* g, size_t n) {
+    CHECK_SCENE(s);
+    if (n && !g) return fail(ZR_E_INVALID, "null group array");
+    s->groups.assign(g, g + n);
+    return ZR_OK;
+}
 int zr_scene_set_materials(zr_scene* s, const zr_material* m, size_t n) {
     CHECK_SCENE(s);
     if (n && !m) return fail(ZR_E_INVALID, "null material array");
@@ -984,6 +1052,7 @@ int zr_scene_set_all(zr_scene* s, const zr_scene_desc* d) {
     if ((rc = zr_scene_set_media(s, d->media, d->n_media))) return rc;
     if ((rc = zr_scene_set_xform_ops(s, d->ops, d->n_ops))) return rc;
     if ((rc = zr_scene_set_objects(s, d->objects, d->n_objects))) return rc;
+    if ((rc = zr_scene_set_groups(s, d->groups, d->n_groups))) return rc;
     if ((rc = zr_scene_set_materials(s, d->materials, d->n_materials))) return rc;
     return zr_scene_set_textures(s, d->textures, d->n_textures, d->texels, d->texel_bytes);
 }
@@ -1003,6 +1072,7 @@ int zr_scene_set_all_borrowed(zr_scene* s, const zr_scene_desc* d) {
     s->texels.borrow((const unsigned char*)d->texels, d->texel_bytes);
     s->borrowed = true;
     int rc;
+    if ((rc = zr_scene_set_groups(s, d->groups, d->n_groups))) return rc;
     if ((rc = zr_scene_set_materials(s, d->materials, d->n_materials))) return rc;   // the small tables are copied: render calls validate against them
     if (d->n_textures && !d->textures) return fail(ZR_E_INVALID, "null texture array");
     s->textures.assign(d->textures, d->textures + d->n_textures);
@@ -1037,8 +1107,28 @@ int zr_scene_commit(zr_scene* s) {
     phase("world list + validate");
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
 
+    // two-level BVH: every group of triangles gets a tree of its own, in its own space, once — however many objects place it
+    std::vector<zr::BuildResult> runs(s->groups.size());
+    std::vector<zr::BuildBox> group_box(s->groups.size());
+    {
+        Boxer tri_boxer{*s};
+        const double ck_tri[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        for (size_t g = 0; g < s->groups.size(); g++) {
+            const zr_group& grp = s->groups[g];
+            std::vector<zr::BuildBox> tb(grp.triangle_count);
+            std::vector<uint32_t> tk(grp.triangle_count, ZR_PRIM_TRIANGLE);
+            zr::BuildBox all; for (int a = 0; a < 3; a++) { all.lo[a] = kInf; all.hi[a] = -kInf; }
+            for (uint32_t k = 0; k < grp.triangle_count; k++) {
+                tb[k] = tri_boxer.prim(ZR_PRIM_TRIANGLE, grp.first_triangle + k);
+                for (int a = 0; a < 3; a++) { all.lo[a] = std::fmin(all.lo[a], tb[k].lo[a]); all.hi[a] = std::fmax(all.hi[a], tb[k].hi[a]); }
+            }
+            group_box[g] = all;
+            zr::build_bvh(tb, tk, 4, ZR_STACK_DEPTH - 2, 1.0, ck_tri, runs[g]);
+            if (runs[g].max_depth >= ZR_STACK_DEPTH - 1) return fail(ZR_E_INVALID, "group %zu: BVH depth %d exceeds the traversal stack", g, runs[g].max_depth);
+        }
+    }
     // boxes + kinds
-    Boxer boxer{*s};
+    Boxer boxer{*s, &group_box};
     std::vector<zr::BuildBox> boxes(objs.size());
     std::vector<uint32_t> kinds(objs.size());
     std::vector<uint8_t> baked(objs.size(), 0);
@@ -1053,6 +1143,7 @@ int zr_scene_commit(zr_scene* s) {
             const zr_object& o = objs[k];
             boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
             kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
+            if (o.type == ZR_PRIM_GROUP) kinds[k] = ZR_KIND_INSTANCE;   // placed as one object, whatever its chain
             if (bake && o.type == ZR_PRIM_TRIANGLE && o.chain_count > 0) {   // see Flattener::append_baked_triangle
                 bool ok = true;
                 for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
@@ -1097,11 +1188,12 @@ int zr_scene_commit(zr_scene* s) {
     if (bad_box.load() != (size_t)-1) return fail(ZR_E_INVALID, "object %zu has a non-finite bounding box", bad_box.load());
     zr::BuildResult br;
     double ck[8] = {env_double("ZR_BVH_COST_SPHERE", 1.0), env_double("ZR_BVH_COST_TRI", 1.5), env_double("ZR_BVH_COST_CUBE", 1.0),
-                    env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), env_double("ZR_BVH_COST_PCUBE", 1.5), 1, 1};
+                    env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), env_double("ZR_BVH_COST_PCUBE", 1.5),
+                    env_double("ZR_BVH_COST_GROUP", 16.0), 1};
     int max_leaf = (int)env_double("ZR_BVH_MAX_LEAF", 4);
     // cubes, media and wrapped objects are few, large and dear to test: one per leaf, so that a ray only tests those whose own box it enters
     const int big = (int)env_double("ZR_BVH_MAX_LEAF_BIG", 1);
-    const int leaf_cap[8] = {0, 0, big, big, big, big, 0, 0};
+    const int leaf_cap[8] = {0, 0, big, big, big, big, big, 0};
     phase("boxes");
     zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br, leaf_cap);
     phase("binned-SAH build");
@@ -1111,6 +1203,7 @@ int zr_scene_commit(zr_scene* s) {
     std::shared_ptr<Flattener> flp(new Flattener{*s, objs, br});
     Flattener& fl = *flp;
     fl.baked = &baked;
+    fl.runs = runs.empty() ? nullptr : &runs;
     fl.open_ratio = env_double("ZR_BVH_OPEN_RATIO", 1.25);
     // the primitive arrays (a quarter of a gigabyte for a million triangles) go to the device while the host still plans and
     // numbers the 4-wide nodes: a thread of its own, joined before the node arrays follow
@@ -1133,6 +1226,7 @@ int zr_scene_commit(zr_scene* s) {
                 if ((r = s->d_pcube_mat.upload(fl.pcube_mat))) return r;
                 if ((r = s->d_media.upload(fl.media))) return r;
                 if ((r = s->d_wrapped.upload(fl.wrapped))) return r;
+                if ((r = s->d_insts.upload(fl.insts))) return r;
                 return ZR_OK;
             };
             up_rc = go();
@@ -1152,7 +1246,7 @@ int zr_scene_commit(zr_scene* s) {
     if (up_rc != ZR_OK) return fail(up_rc, "%s", up_err.c_str());
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
     s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
-                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24);
+                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24) && fl.insts.size() < (1u << 24);
     if ((rc = s->d_ops.upload(s->ops.data(), s->ops.size()))) return rc;
     {
         // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
@@ -1181,7 +1275,7 @@ int zr_scene_commit(zr_scene* s) {
     d.tri_v = s->d_tri_v.p; d.tri_s = s->d_tri_s.p;
     d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
     d.pcubes = s->d_pcubes.p; d.pcube_mat = s->d_pcube_mat.p;
-    d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.ops = s->d_ops.p;
+    d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.insts = s->d_insts.p; d.ops = s->d_ops.p;
     d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
     d.n_mats = (uint32_t)s->materials.size();
     d.mat_kinds = 0;
@@ -1190,11 +1284,12 @@ int zr_scene_commit(zr_scene* s) {
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         bool plain_media = true;   // media whose boundary is an unwrapped sphere or cube
         for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) plain_media = false;
-        if (!fl.wrapped.empty() || !plain_media) s->leaf_level = 2;
+        if (!fl.insts.empty()) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
+        else if (!fl.wrapped.empty() || !plain_media) s->leaf_level = 2;
         else if (!fl.cubes.empty() || !fl.pcube_mat.empty() || !fl.media.empty()) s->leaf_level = 1;
         else s->leaf_level = 0;
         const int force = (int)env_double("ZR_EXTEND_LEVEL", -1);
-        if (force > s->leaf_level && force <= 2) s->leaf_level = force;
+        if (force > s->leaf_level && force <= 3) s->leaf_level = force;
     }
     s->stack_demand = fl.stack_demand();
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", fl.quad_depth, s->stack_demand);
@@ -1209,10 +1304,10 @@ int zr_scene_commit(zr_scene* s) {
     phase("upload");
     {   // unmapping half a gigabyte of staging arrays takes tens of milliseconds: not on the caller's clock
         struct Trash { std::shared_ptr<Flattener> fl; zr::BuildResult br; std::vector<zr::BuildBox> boxes; std::vector<zr_object> objs;
-                       std::vector<uint32_t> kinds; std::vector<uint8_t> baked; };
+                       std::vector<uint32_t> kinds; std::vector<uint8_t> baked; std::vector<zr::BuildResult> runs; };
         auto t = std::make_shared<Trash>();
         fl.after_primitives = nullptr;   // (it captures locals of this call)
-        t->fl = std::move(flp); t->br = std::move(br); t->boxes = std::move(boxes); t->objs = std::move(objs); t->kinds = std::move(kinds); t->baked = std::move(baked);
+        t->fl = std::move(flp); t->br = std::move(br); t->boxes = std::move(boxes); t->objs = std::move(objs); t->kinds = std::move(kinds); t->baked = std::move(baked); t->runs = std::move(runs);
         try { std::thread([t]() mutable { t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
     }
     phase("release");

@@ -32,6 +32,7 @@ void* zrs_build(const char* name, int a0, int a1, int a2, int a3) {
     if (!ok) { delete h; return nullptr; }
     zenith::scene_builder b(h->fs);
     h->s.world.flatten(b);
+    b.finish();
     h->env = zenith::to_zr_env(h->s.env, b);
     for (const auto& t : h->s.kat_textures) h->kat_tex.push_back(b.texture_id(t));
     h->desc = h->fs.desc();

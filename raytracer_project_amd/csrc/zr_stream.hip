@@ -144,6 +144,7 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
 //   0  bare triangles and spheres (cfg2, cfg3)
 //   1  + bare cubes, placed cubes (cube -> [rotate_y] -> translate) and media in an unwrapped sphere or cube (cfg5)
 //   2  + objects under arbitrary wrapper chains and wrapped media (the op-list interpreter)
+//   3  + placed runs of triangles (two-level BVH: zr_device.h instance_t; its private stack costs this build registers)
 // Stack: ST_LDS_STACK entries per lane in LDS, deeper ones in this wave's slab of `overflow` (ovf_levels x 64 entries); the
 // host sizes the slab from the exact worst-case demand of the committed tree (Flattener::stack_demand), so no push can
 // leave it.
@@ -155,7 +156,7 @@ __device__ __forceinline__ void cswap(float& ta, uint32_t& ra, float& tb, uint32
 #define ST_EXT_GROUP 1
 #endif
 template <bool COUNT, int LEVEL>
-__global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
+__global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEVEL == 1 ? ST_EXT_WAVES_MID : ST_EXT_WAVES_LEAN)) void stream_extend(DScene sc, StreamBuf B, SEntry* __restrict__ overflow,
                                                                   uint32_t ovf_levels, unsigned long long* __restrict__ gctr) {
     __shared__ SEntry lstack[ST_EXT_GROUP * ST_LDS_STACK * 64];
     const int lane = threadIdx.x & 63;
@@ -391,6 +392,11 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL == 2 ? ST_EXT_WAVES : (LEV
                     if (lkind == ZR_KIND_PCUBE) h = pcube_t(sc.pcubes + (size_t)prim * 12, ray, 0.001, tbest, t);
                     else if (lkind == ZR_PRIM_CUBE) h = cube_t(sc.cubes + (size_t)prim * 6, ray, 0.001, tbest, t);
                     else h = medium_plain_t(sc, prim, ray, 0.001, tbest, g, t);
+                } else if (LEVEL == 3 && lkind == ZR_KIND_INSTANCE) {   // a placed run of triangles: its own tree, walked right here with the mapped ray
+                    uint32_t tri = 0, nb = 0, nt = 0;
+                    h = instance_t(sc, prim, ray, 0.001, tbest, t, tri, nb, nt);
+                    if (COUNT) { c_nodes += nb; c_tri += nt; c_med--; }
+                    if (h) { tbest = t; tbest_f = __double2float_ru(t); kbest = ZR_KIND_INSTANCE | (prim << 8); ibest = tri; h = false; }
                 } else h = object_t(sc, lkind, prim, ray, 0.001, tbest, g, t);
                 if (h) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                 tested = true;
@@ -810,7 +816,8 @@ template <bool COUNT>
 static void launch_extend(const DScene& sc, const StreamBuf& B, void* overflow, uint32_t ovf_levels, int blocks, unsigned long long* gctr, int level, hipStream_t st) {
     // `blocks` counts waves (at most stream_extend_blocks(), a multiple of ST_EXT_GROUP: the overflow slabs are sized for that many)
     const dim3 grid((blocks + ST_EXT_GROUP - 1) / ST_EXT_GROUP), group(64 * ST_EXT_GROUP);
-    if (level >= 2) hipLaunchKernelGGL((stream_extend<COUNT, 2>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    if (level >= 3) hipLaunchKernelGGL((stream_extend<COUNT, 3>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
+    else if (level == 2) hipLaunchKernelGGL((stream_extend<COUNT, 2>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
     else if (level == 1) hipLaunchKernelGGL((stream_extend<COUNT, 1>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
     else hipLaunchKernelGGL((stream_extend<COUNT, 0>), grid, group, 0, st, sc, B, (SEntry*)overflow, ovf_levels, gctr);
 }

@@ -20,7 +20,7 @@ REL_TOL = 1e-4      # north_star: "within 1e-4 relative per-channel"
 ABS_FLOOR = 1e-7    # radiance below this is treated as 0 for the relative comparison
 
 TILE_FIXTURES = ["cfg1_full", "cfg1_tile", "cfg2_tile", "cfg2_tile_b", "cfg3_small", "cfg3_full", "cfg5_tile",
-                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
+                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
 
 
 @pytest.fixture(scope="module")
@@ -81,7 +81,7 @@ def test_radiance_matches_reference(name, count, ctx):
 
 
 @pytest.mark.parametrize("engine", ["extend", "pairs"])
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_demo", "trace_cfg3w_small",
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_demo", "trace_cfg3w_small",
                                   "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records, through both
@@ -429,6 +429,32 @@ def test_pipeline_shape_does_not_change_the_image(var, values, built, monkeypatc
             assert np.array_equal(frames[0], f) and ctrs[0] == k, (name, var)
 
 
+def test_shared_mesh_is_stored_once(built, monkeypatch):
+    """Two-level BVH: inst0 places one 960-triangle mesh 36 times and a 13-triangle one 8 times.  Flattened with groups the world
+    list has 46 entries and the device holds each mesh once; with ZR_GROUPS=0 every placement is a baked copy of every triangle.
+    Same picture (the two differ in the last bits only: a ray mapped into the mesh's space against vertices mapped out of it)."""
+    from raytracer_project_amd import capi
+    frames, sizes, entries = [], [], []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("ZR_GROUPS", groups)
+        ds = capi.DemoScene("inst0")
+        entries.append((ds.desc.n_objects, ds.desc.n_groups, ds.desc.n_tris))
+        c = capi.Context(0)
+        try:
+            sc = capi.Scene(c, ds.desc)
+            sizes.append(sc.stats()["device_bytes"])
+            frames.append(sc.render(ds.camera, ds.env, ds.seed, None, count=True))
+            k = c.counters()
+            assert k.primary_samples == ds.camera.image_width * ds.camera.image_height * ds.camera.samples_per_pixel
+            sc.close()
+        finally:
+            c.close()
+    assert entries[0] == (46, 2, 973) and entries[1][1] == 0 and entries[1][0] == 2 + 36 * 960 + 8 * 13
+    assert sizes[0] * 8 < sizes[1], sizes
+    err = rel_err(frames[0], frames[1])
+    assert (err > REL_TOL).sum() == 0, float(err.max())
+
+
 def test_bench_line_contract(built):
     """bench.py on the reference's own CPU-sized case: one JSON line with the driver's keys, the roofline object (incl. the
     random-record rate the traversal kernel runs against) and a CPU baseline whose port reproduces the reference's counts."""
@@ -498,7 +524,7 @@ def test_full_size_properties(name, ctx):
         _check(full[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]], fx["mean"], fx_name + " inside the full frame")
 
 
-@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0"])
+@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0", "aov_inst0"])
 def test_aov_passes_match_reference(name, ctx):
     """zr_render_aov (albedo / camera-space normal / z-depth of the primary hits) vs the genuine reference."""
     from raytracer_project_amd import capi
