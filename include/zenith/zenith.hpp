@@ -264,13 +264,15 @@ public:
         auto it = run_ids.find(identity);
         if (it == run_ids.end()) {
             std::vector<zr_xform_op> outer; outer.swap(chain);
-            const size_t first = fs.tri_mat.size();
+            const size_t first = fs.tri_mat.size(), n_sph = fs.sphere_mat.size(), n_cube = fs.cube_mat.size(), n_med = fs.media.size(), n_ops = fs.ops.size();
             in_run = true; run_ok = true;
             children();
             in_run = false; chain.swap(outer);
             const size_t n = fs.tri_mat.size() - first;
-            if (!run_ok || n == 0) {   // not a run of bare triangles: forget what was captured and flatten it in place
+            if (!run_ok || n == 0) {   // not a run of bare triangles: forget everything the capture appended and flatten the child in place
                 fs.tri_v.resize(first * 9); fs.tri_n.resize(first * 9); fs.tri_mat.resize(first);
+                fs.spheres.resize(n_sph * 4); fs.sphere_mat.resize(n_sph); fs.cubes.resize(n_cube * 12); fs.cube_mat.resize(n_cube);
+                fs.media.resize(n_med); fs.ops.resize(n_ops);
                 run_ids[identity] = 0xFFFFFFFFu;
                 children();
                 return;
@@ -328,10 +330,8 @@ private:
     void emit(uint32_t type, uint32_t index) {
         zr_object o{};
         o.type = type; o.index = index;
-        if (in_run) {   // a group's own triangle: not a world-list entry; anything else (or a wrapper inside) ends the capture
-            if (type != ZR_PRIM_TRIANGLE || !chain.empty()) run_ok = false;
-            return;
-        }
+        if (in_run && (type != ZR_PRIM_TRIANGLE || !chain.empty() || in_boundary)) run_ok = false;   // only bare triangles make a group
+        if (in_run && !in_boundary) return;   // a group's own triangle is not a world-list entry
         if (in_boundary) {
             o.chain_count = (uint32_t)(chain.size() - boundary_base);
             o.chain_first = copy_chain(boundary_base, chain.size());

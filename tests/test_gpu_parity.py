@@ -20,7 +20,7 @@ REL_TOL = 1e-4      # north_star: "within 1e-4 relative per-channel"
 ABS_FLOOR = 1e-7    # radiance below this is treated as 0 for the relative comparison
 
 TILE_FIXTURES = ["cfg1_full", "cfg1_tile", "cfg2_tile", "cfg2_tile_b", "cfg3_small", "cfg3_full", "cfg5_tile",
-                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
+                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "inst1_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
 
 
 @pytest.fixture(scope="module")
@@ -81,7 +81,7 @@ def test_radiance_matches_reference(name, count, ctx):
 
 
 @pytest.mark.parametrize("engine", ["extend", "pairs"])
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_demo", "trace_cfg3w_small",
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_inst1", "trace_demo", "trace_cfg3w_small",
                                   "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_hit_records_match_reference(name, engine, ctx, monkeypatch):
     """world.hit() known answers on the device (zr_trace) vs the genuine reference's hit records, through both
