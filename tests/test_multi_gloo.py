@@ -55,8 +55,12 @@ def test_tile_sharding_gloo(exchange, world, tile, built, tmp_path):
     script.write_text(WORKER)
     out = tmp_path / "frame.npy"
     env = dict(os.environ, ZR_ROOT=ROOT, ZR_OUT=str(out), OMP_NUM_THREADS="1", ZR_MULTI_EXCHANGE=exchange, ZR_TILE=str(tile))
+    import socket
+    with socket.socket() as sk:   # a free port per case: back-to-back launches on one fixed port met its TIME_WAIT now and then
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(script)]
+           "--master-port", str(port), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     tiles = sorted(int(l.split()[-1]) for l in p.stdout.splitlines() if l.startswith("rank"))
