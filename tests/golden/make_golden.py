@@ -76,6 +76,7 @@ PASSES = {
     "passes_mix2": ("mix2", 0, 0, 64, 48, 16, []),
     "passes_cfg2": ("cfg2", 560, 280, 48, 32, 32, []),
     "passes_cfg5": ("cfg5", 150, 350, 32, 24, 32, []),
+    "passes_inst0": ("inst0", 16, 8, 96, 64, 16, []),
 }
 
 # the post stack (bloom, sharpen, process, 8-bit; analyze_framebuffer) through the genuine post_processor / bloom_filter:

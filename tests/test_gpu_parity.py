@@ -542,7 +542,7 @@ def test_aov_passes_match_reference(name, ctx):
     assert not a[outside].any() and not n[outside].any() and not z[outside].any()
 
 
-@pytest.mark.parametrize("name", ["passes_mix0", "passes_mix2", "passes_cfg2", "passes_cfg5"])
+@pytest.mark.parametrize("name", ["passes_mix0", "passes_mix2", "passes_cfg2", "passes_cfg5", "passes_inst0"])
 def test_reflection_refraction_passes_match_reference(name, ctx):
     """zr_render_passes (beauty + reflection / refraction split, camera.hpp:490-517) vs the genuine reference; segment and
     RNG-draw counts of both paths bit-exact; the beauty frame equals zr_render's image bit for bit."""
@@ -568,7 +568,7 @@ def test_reflection_refraction_passes_match_reference(name, ctx):
     _check(b[sl], plain[sl], name + " beauty vs zr_render")
 
 
-@pytest.mark.parametrize("name", ["mix0", "mix1", "mix2", "cfg2", "cfg5", "mesh0", "demo"])
+@pytest.mark.parametrize("name", ["mix0", "mix1", "mix2", "cfg2", "cfg5", "mesh0", "demo", "inst0", "inst1"])
 def test_path_records_match_oracle(name, ctx):
     """zr_trace_paths: every segment of 3000 primary samples — ray, hit, material, scatter decision, attenuation, emission
     and the number of RNG draws consumed — against the CPU oracle walking the same samples.  This is the device-side
@@ -588,6 +588,8 @@ def test_path_records_match_oracle(name, ctx):
         bad = np.argwhere(g[:, :, col] != o[:, :, col])
         assert len(bad) == 0, f"{what}: {len(bad)} segments differ, first at request {req[bad[0][0]]} segment {bad[0][1]}"
     tol = 1e-7   # last-bit differences (fused multiply-add, libm) grow along a path of up to 24 refractions; decisions stay exact
+    if name.startswith("inst"):
+        tol = 1e-6   # ... and faster between the curved fuzz-0 mirrors of the instanced knots (1.5e-7 seen after eight bounces)
     for cols, what in ((slice(0, 6), "ray"), (slice(7, 8), "t"), (slice(10, 13), "attenuation"), (slice(13, 16), "emission")):
         err = np.abs(g[:, :, cols] - o[:, :, cols]) / np.maximum(1.0, np.abs(o[:, :, cols]))
         assert err.max() < tol, f"{what}: max error {err.max():.3e}"
@@ -595,7 +597,7 @@ def test_path_records_match_oracle(name, ctx):
 
 
 @pytest.mark.parametrize("variant", [0])
-@pytest.mark.parametrize("name", ["cfg1_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full", "mix1_full", "mesh0_full", "demo_tile_b"])
+@pytest.mark.parametrize("name", ["cfg1_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full", "mix1_full", "mesh0_full", "inst0_full", "inst1_full", "demo_tile_b"])
 def test_other_kernel_variants_match_reference(name, variant, built, monkeypatch):
     """ZR_KERNEL=0, the pixel-group megakernel that renders frames beyond the streaming pipeline's packing limits, shares the device
     arithmetic with the pipeline but walks the pair BVH and integrates in registers: same fixtures, same bar."""

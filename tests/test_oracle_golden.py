@@ -115,7 +115,7 @@ def test_oracle_matches_reference_aov(name, built):
     assert a.max() > 0.5 and 0.0 <= z.min() and z.max() <= 1.0
 
 
-@pytest.mark.parametrize("name", ["passes_mix0", "passes_mix2", "passes_cfg2", "passes_cfg5"])
+@pytest.mark.parametrize("name", ["passes_mix0", "passes_mix2", "passes_cfg2", "passes_cfg5", "passes_inst0"])
 def test_oracle_matches_reference_passes(name, built):
     """Beauty / reflection / refraction with the split flags on (camera.hpp:490-517: the first hit is scattered a second
     time with the draws that follow the beauty path, a second path is traced, luma-clamped and classified): bit-identical
