@@ -58,7 +58,7 @@ struct DMedium {
     double neg_inv_density;
 };
 struct DWrapped { uint32_t type, index, chain_first, chain_count; };
-struct DInstance { uint32_t chain_first, chain_count, root /* pair index of the run's subtree in DScene::nodes */, pad_; };
+struct DInstance { uint32_t chain_first, chain_count, root /* pair index of the run's subtree in DScene::nodes */, pad_ /* = qroot: the run's root among DScene::quads */; };
 
 struct DScene {
     const NodePair* nodes;

@@ -315,8 +315,11 @@ struct Flattener {
     zr::RawArray<zr::DMedium> media;
     zr::RawArray<zr::DWrapped> wrapped;
     zr::RawArray<zr::DInstance> insts;
+    std::vector<uint32_t> inst_group;                     // per placement: its group
     const std::vector<zr::BuildResult>* runs = nullptr;   // per zr_group: the tree over its triangles (object space), built by the caller
     std::vector<uint32_t> run_root;                       // per group: pair index of its subtree's root
+    std::vector<uint32_t> run_tri_base, run_qroot, run_demand;   // per group: first triangle (device index), its root among the 4-wide nodes, its worst-case stack entries
+    bool root_in_array = false;                           // a group's own flattener: the root is a quantised node like any other (quads[0])
     size_t n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0;   // filled sizes (the arrays are sized exactly)
     std::function<void()> after_primitives;   // called by run() once spheres / triangles / cubes / media / wrapped are complete
     const std::vector<uint8_t>* baked = nullptr;   // per object: 0 as is, 1 baked triangle, 2 material-only chain, 3 baked sphere, 4 placed cube
@@ -478,7 +481,7 @@ struct Flattener {
     void put_leaf_object(uint32_t oi, size_t di) {
         const zr_object& o = objs[oi];
         const uint8_t bk = baked ? (*baked)[oi] : 0;
-        if (o.type == ZR_PRIM_GROUP) { zr::DInstance in{}; in.chain_first = o.chain_first; in.chain_count = o.chain_count; in.root = run_root[o.index]; insts[di] = in; }
+        if (o.type == ZR_PRIM_GROUP) { zr::DInstance in{}; in.chain_first = o.chain_first; in.chain_count = o.chain_count; in.root = run_root[o.index]; insts[di] = in; inst_group[di] = o.index; }
         else if (bk == 1) put_baked_triangle(di, o);
         else if (bk == 3) put_baked_sphere(di, o);
         else if (bk == 4) put_pcube(di, o);
@@ -505,11 +508,17 @@ struct Flattener {
     uint32_t emit_run(uint32_t g, uint32_t base) {
         const zr::BuildResult& rb = (*runs)[g];
         const zr_group& grp = s.groups[g];
-        auto leaf_tris = [&](const zr::BuildNode& n) {   // -> first device index
-            const uint32_t first = (uint32_t)n_tri;
+        // the run's triangles in the order of its leaves by ascending node id — the order index_nodes() gives a tree's leaves, so that
+        // the run's 4-wide nodes (emit_run_quads, numbered by a flattener of their own) name the same indices
+        run_tri_base[g] = (uint32_t)n_tri;
+        std::vector<uint32_t> first_of(rb.nodes.size(), 0);
+        for (size_t id = 0; id < rb.nodes.size(); id++) {
+            const zr::BuildNode& n = rb.nodes[id];
+            if (!n.count) continue;
+            first_of[id] = (uint32_t)n_tri;
             for (uint32_t k = 0; k < n.count; k++) { put_triangle(n_tri, grp.first_triangle + rb.order[n.first + k]); n_tri++; }
-            return first;
-        };
+        }
+        auto leaf_tris = [&](const zr::BuildNode& n) { return first_of[(size_t)(&n - &rb.nodes[0])]; };
         if (rb.nodes[0].count) {
             const zr::BuildNode& n = rb.nodes[0];
             for (int k = 0; k < 3; k++) { pairs[base].lo[0][k] = f_down(n.box.lo[k]); pairs[base].hi[0][k] = f_up(n.box.hi[k]); }
@@ -720,7 +729,7 @@ struct Flattener {
         plan.allocate(br.nodes.size());
         levels.clear();
         levels.push_back(std::vector<int32_t>{root_id});
-        bool first = true;
+        bool first = !root_in_array;
         for (;;) {
             const std::vector<int32_t>& level = levels.back();
             const int T = std::max(1, threads);
@@ -754,8 +763,8 @@ struct Flattener {
                 }
             });
         }
-        const size_t n_quads = (size_t)q_size[root_id] - 1;   // the root travels in the kernel arguments
-        q_index[root_id] = 0xFFFFFFFFu;                        // so that its first child becomes node 0
+        const size_t n_quads = (size_t)q_size[root_id] - (root_in_array ? 0 : 1);   // the world's root travels in the kernel arguments
+        q_index[root_id] = root_in_array ? 0u : 0xFFFFFFFFu;                        // ... so that its first child becomes node 0
         quads.resize(n_quads);
         for (size_t l = 0; l < levels.size(); l++) {           // top-down: indices, and the records themselves
             const std::vector<int32_t>& level = levels[l];
@@ -770,7 +779,7 @@ struct Flattener {
                         if (n.count) refs[k] = ZR_REF_LEAF | ((uint32_t)n.kind << 28) | ((uint32_t)(n.count - 1u) << 24) | leaf_first[qp.kids[k]];
                         else { refs[k] = next; q_index[qp.kids[k]] = next; next += q_size[qp.kids[k]]; }
                     }
-                    if (l == 0) {
+                    if (l == 0 && !root_in_array) {
                         for (int k = 0; k < qp.nk; k++) {
                             const zr::BuildBox& bb = br.nodes[qp.kids[k]].box;
                             root.lox[k] = f_down(bb.lo[0]); root.loy[k] = f_down(bb.lo[1]); root.loz[k] = f_down(bb.lo[2]);
@@ -796,7 +805,14 @@ struct Flattener {
         uint32_t nk = 0, best = 0;
         for (int k = 0; k < 4; k++) if (refs[k] != ZR_REF_EMPTY) nk++;
         for (int k = 0; k < 4; k++) {
-            if (refs[k] == ZR_REF_EMPTY || (refs[k] & ZR_REF_LEAF)) continue;
+            if (refs[k] == ZR_REF_EMPTY) continue;
+            if (refs[k] & ZR_REF_LEAF) {   // a placed run: one sentinel entry, then the run's own tree on the same stack (zr_stream.hip, level 3)
+                if (((refs[k] >> 28) & 7u) == ZR_KIND_INSTANCE && !run_demand.empty() && !insts.empty()) {
+                    const uint32_t g = inst_group[refs[k] & 0xFFFFFFu];
+                    best = std::max(best, 1u + run_demand[g]);
+                }
+                continue;
+            }
             best = std::max(best, demand_of(quads[refs[k]].ref));
         }
         return std::max(nk, nk ? nk - 1 + best : 0u);
@@ -846,11 +862,11 @@ struct Flattener {
         n_media = cnt[ZR_PRIM_MEDIUM]; n_wrapped = cnt[ZR_KIND_WRAPPED];
         size_t run_pair_total = 0;
         if (runs) for (size_t g = 0; g < runs->size(); g++) { x_tri += s.groups[g].triangle_count; run_pair_total += run_pairs((*runs)[g]); }
-        insts.allocate(cnt[ZR_KIND_INSTANCE]);
+        insts.allocate(cnt[ZR_KIND_INSTANCE]); inst_group.assign(cnt[ZR_KIND_INSTANCE], 0);
         const size_t main_pairs = std::max<size_t>(1, inner.size());
         pairs.allocate(main_pairs + run_pair_total);
         if (runs) {   // where each group's subtree will start (the records follow the world's own)
-            run_root.resize(runs->size());
+            run_root.resize(runs->size()); run_tri_base.assign(runs->size(), 0);
             size_t at = main_pairs;
             for (size_t g = 0; g < runs->size(); g++) { run_root[g] = (uint32_t)at; at += run_pairs((*runs)[g]); }
         }
@@ -898,6 +914,48 @@ struct Flattener {
         ph("4-wide plan");
         number_quads(0);
         ph("4-wide numbering");
+        if (runs) { emit_run_quads(); ph("groups' 4-wide nodes"); }
+    }
+    // The 4-wide quantised nodes of every group, behind the world's own: planned and numbered by a flattener of the group's tree
+    // (same collapse, same quantisation; its root is a stored node, not kernel arguments), then copied with the indices moved —
+    // inner references by the group's first node, triangle references by the group's first triangle.  Placements get the root.
+    void emit_run_quads() {
+        run_qroot.assign(runs->size(), 0); run_demand.assign(runs->size(), 0);
+        const std::vector<zr_object> none;
+        for (size_t g = 0; g < runs->size(); g++) {
+            const zr::BuildResult& rb = (*runs)[g];
+            Flattener sub{s, none, rb};
+            sub.threads = 1; sub.open_ratio = open_ratio; sub.root_in_array = true;
+            sub.leaf_first.allocate(rb.nodes.size()); sub.pair_of.allocate(rb.nodes.size());
+            const uint32_t base = (uint32_t)quads.size();
+            run_qroot[g] = base;
+            if (rb.nodes[0].count) {   // the whole run is one leaf: a node with one child
+                zr::NodeQ nq{};
+                int32_t kid = 0; double w = 1;
+                for (int ax = 0; ax < 3; ax++) nq.scale[ax] = 1;
+                if (!sub.quantise(&kid, 1, nq, &w)) quant_ok_a = false;
+                for (int k = 0; k < 4; k++) nq.ref[k] = ZR_REF_EMPTY;
+                nq.ref[0] = ZR_REF_LEAF | ((uint32_t)ZR_PRIM_TRIANGLE << 28) | ((uint32_t)(rb.nodes[0].count - 1u) << 24) | run_tri_base[g];
+                quads.push_back(nq);
+                run_demand[g] = 1;
+                continue;
+            }
+            sub.index_nodes();
+            sub.plan_quads(0);
+            sub.number_quads(0);
+            if (!sub.quant_ok) quant_ok_a = false;
+            for (zr::NodeQ nq : sub.quads) {
+                for (int k = 0; k < 4; k++) {
+                    if (nq.ref[k] == ZR_REF_EMPTY) continue;
+                    if (nq.ref[k] & ZR_REF_LEAF) nq.ref[k] += run_tri_base[g];   // (the low 24 bits: the first primitive)
+                    else nq.ref[k] += base;
+                }
+                quads.push_back(nq);
+            }
+            run_demand[g] = sub.demand_of(sub.quads[0].ref) + 0u;
+        }
+        quant_ok = quant_ok && quant_ok_a.load();
+        for (size_t i = 0; i < insts.size(); i++) insts[i].pad_ = run_qroot[inst_group[i]];   // DInstance::qroot
     }
     void fill_leaf_root() {   // the whole world in one leaf: a pair whose second child is empty
         const zr::BuildNode& n = br.nodes[0];
@@ -1193,7 +1251,7 @@ int zr_scene_commit(zr_scene* s) {
     int max_leaf = (int)env_double("ZR_BVH_MAX_LEAF", 4);
     // cubes, media and wrapped objects are few, large and dear to test: one per leaf, so that a ray only tests those whose own box it enters
     const int big = (int)env_double("ZR_BVH_MAX_LEAF_BIG", 1);
-    const int leaf_cap[8] = {0, 0, big, big, big, big, big, 0};
+    const int leaf_cap[8] = {0, 0, big, big, big, big, 1, 0};   // a placement is always a leaf of its own (EXTEND enters it as a whole)
     phase("boxes");
     zr::build_bvh(boxes, kinds, max_leaf, ZR_STACK_DEPTH - 2, env_double("ZR_BVH_COST_TRAVERSE", 1.0), ck, br, leaf_cap);
     phase("binned-SAH build");
@@ -1226,7 +1284,6 @@ int zr_scene_commit(zr_scene* s) {
                 if ((r = s->d_pcube_mat.upload(fl.pcube_mat))) return r;
                 if ((r = s->d_media.upload(fl.media))) return r;
                 if ((r = s->d_wrapped.upload(fl.wrapped))) return r;
-                if ((r = s->d_insts.upload(fl.insts))) return r;
                 return ZR_OK;
             };
             up_rc = go();
@@ -1239,6 +1296,7 @@ int zr_scene_commit(zr_scene* s) {
 
     if ((rc = s->d_nodes.upload(fl.pairs))) return rc;
     if ((rc = s->d_quads.upload(fl.quads))) return rc;
+    if ((rc = s->d_insts.upload(fl.insts))) return rc;   // (after the groups' nodes were numbered: a placement names its group's root)
     if (uploader.joinable()) uploader.join();
     else if (fl.after_primitives) {   // a world without nodes returned from run() before the hook: upload the (empty) arrays here
         fl.after_primitives(); if (uploader.joinable()) uploader.join();

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
     double tbest = INF;
     float tbest_f = INFf;
     uint32_t kbest = NONE, ibest = 0;
+    uint32_t inst_cur = 0;  // level 3: 0 = the lane walks the world's tree with the world ray; p + 1 = it is inside placement p, with the ray mapped into the run's space
     uint32_t cur = 0;       // X_NODE: quad index; X_LEAF: leaf reference (kind << 28 | (count - 1) << 24 | first)
     uint32_t pend_i = 0;
     int sp = 0;
@@ -226,6 +227,20 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
         if (COUNT && !empty_) c_nodes++;                                                                    \
         TN = hit_ ? n_ : INFf;                                                                              \
         RF = (RF_IN);                                                                                       \
+    }
+// the slab constants of `ray` (see the header comment of this kernel)
+#define ZR_RAY_CONSTANTS()                                                                                  \
+    {                                                                                                       \
+        const float NANf = __builtin_nanf("");                                                              \
+        idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;            \
+        float ocx = (float)(-ray.o.x * (double)idx_), ocy = (float)(-ray.o.y * (double)idy_), ocz = (float)(-ray.o.z * (double)idz_); \
+        /* 2^100 / 2^120: far inside the float range, so that no product with a plane or a scale overflows */ \
+        if (!(fabsf(idx_) < 1.2676506e30f) || !(fabsf(ocx) < 1.3292280e36f)) { idx_ = 0.0f; ocx = NANf; }    \
+        if (!(fabsf(idy_) < 1.2676506e30f) || !(fabsf(ocy) < 1.3292280e36f)) { idy_ = 0.0f; ocy = NANf; }    \
+        if (!(fabsf(idz_) < 1.2676506e30f) || !(fabsf(ocz) < 1.3292280e36f)) { idz_ = 0.0f; ocz = NANf; }    \
+        /* the lower plane is the entry plane when id > 0: it gets the smaller constant */                   \
+        const float sx = copysignf(fabsf(ocx) * 2.3841858e-7f, idx_), sy = copysignf(fabsf(ocy) * 2.3841858e-7f, idy_), sz = copysignf(fabsf(ocz) * 2.3841858e-7f, idz_); \
+        clx = ocx - sx; chx = ocx + sx; cly = ocy - sy; chy = ocy + sy; clz = ocz - sz; chz = ocz + sz;      \
     }
 #define ZR_FBOX(N, C, TN, RF)                                                                               \
     ZR_SLAB(fmaf((N).lox[C], idx_, clx), fmaf((N).hix[C], idx_, chx), fmaf((N).loy[C], idy_, cly), fmaf((N).hiy[C], idy_, chy), \
@@ -301,19 +316,8 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                         slot = my;
                         if (LEVEL > 0) { ray.o = ro_; ray.d = rd_; } else { ray.o = B.ld3(SF_RAY, my); ray.d = B.ld3(SF_RAY + 3, my); }
                         if (LEVEL > 0) { g.key = (uint64_t)__double_as_longlong(key_); g.bounce = m.y & 0xFFu; }
-                        {
-                            const float NANf = __builtin_nanf("");
-                            idx_ = 1.0f / (float)ray.d.x; idy_ = 1.0f / (float)ray.d.y; idz_ = 1.0f / (float)ray.d.z;
-                            float ocx = (float)(-ray.o.x * (double)idx_), ocy = (float)(-ray.o.y * (double)idy_), ocz = (float)(-ray.o.z * (double)idz_);
-                            // 2^100 / 2^120: far inside the float range, so that no product with a plane or a scale overflows
-                            if (!(fabsf(idx_) < 1.2676506e30f) || !(fabsf(ocx) < 1.3292280e36f)) { idx_ = 0.0f; ocx = NANf; }
-                            if (!(fabsf(idy_) < 1.2676506e30f) || !(fabsf(ocy) < 1.3292280e36f)) { idy_ = 0.0f; ocy = NANf; }
-                            if (!(fabsf(idz_) < 1.2676506e30f) || !(fabsf(ocz) < 1.3292280e36f)) { idz_ = 0.0f; ocz = NANf; }
-                            // the lower plane is the entry plane when id > 0: it gets the smaller constant
-                            const float sx = copysignf(fabsf(ocx) * 2.3841858e-7f, idx_), sy = copysignf(fabsf(ocy) * 2.3841858e-7f, idy_), sz = copysignf(fabsf(ocz) * 2.3841858e-7f, idz_);
-                            clx = ocx - sx; chx = ocx + sx; cly = ocy - sy; chy = ocy + sy; clz = ocz - sz; chz = ocz + sz;
-                        }
-                        tbest = INF; tbest_f = INFf; kbest = NONE; cur = 0; sp = 0; pend_i = 0;
+                        ZR_RAY_CONSTANTS()
+                        tbest = INF; tbest_f = INFf; kbest = NONE; cur = 0; sp = 0; pend_i = 0; inst_cur = 0;
                         if (COUNT) c_seg++;
                         // the root's FP32 boxes come with the kernel arguments: no memory access for the first step, and a
                         // ray that misses the whole world is finished right here
@@ -370,7 +374,10 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                 if (is_leaf && lkind == ZR_PRIM_TRIANGLE) {
                     double t;
                     if (COUNT) c_tri++;
-                    if (triangle_t(sc.tri_v + (size_t)prim * ZR_TRI_STRIDE, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
+                    if (triangle_t(sc.tri_v + (size_t)prim * ZR_TRI_STRIDE, ray, 0.001, tbest, t)) {
+                        tbest = t; tbest_f = __double2float_ru(t); ibest = prim;
+                        kbest = (LEVEL == 3 && inst_cur) ? (ZR_KIND_INSTANCE | ((inst_cur - 1u) << 8)) : lkind;   // a triangle of a placed run: kind word = placement
+                    }
                     tested = true;
                 }
             } else if (do_sph) {
@@ -382,24 +389,37 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                 }
             } else if (LEVEL > 0 && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
                 double t;
-                if (COUNT) {
+                if (COUNT && lkind < ZR_KIND_INSTANCE) {
                     uint32_t kk = lkind;
                     if (kk == ZR_KIND_WRAPPED) kk = sc.wrapped[prim].type;
                     if (kk == ZR_PRIM_SPHERE) c_sph++; else if (kk == ZR_PRIM_TRIANGLE) c_tri++; else if (kk == ZR_PRIM_CUBE || kk == ZR_KIND_PCUBE) c_cube++; else c_med++;
                 }
                 bool h;
+                if (LEVEL == 3 && lkind == ZR_KIND_INSTANCE) {
+                    // ENTER a placed run of triangles (two-level BVH): a sentinel stays on the stack where the world's walk goes on, the
+                    // ray is mapped through the placement's wrappers (t is the same in both spaces: the reference's wrappers do not
+                    // renormalise the direction) and the lane continues in the run's own 4-wide tree — same loop, same stack
+                    const DInstance in = sc.insts[prim];
+                    ZR_PUSH(ZR_REF_LEAF | (7u << 28), -INFf)
+                    ray = chain_ray(sc, in.chain_first, in.chain_count, ray);
+                    ZR_RAY_CONSTANTS()
+                    inst_cur = prim + 1u;
+                    cur = in.pad_; pend_i = 0; st = X_NODE;
+                } else if (LEVEL == 3 && lkind == 7u) {
+                    // LEAVE: the run's tree is exhausted (its entries were above the sentinel); the world ray again, from the slot
+                    ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
+                    ZR_RAY_CONSTANTS()
+                    inst_cur = 0;
+                    ZR_POP_NEXT()
+                } else {
                 if (LEVEL == 1) {   // cubes, placed cubes, plain media: no op-list interpreter in this build
                     if (lkind == ZR_KIND_PCUBE) h = pcube_t(sc.pcubes + (size_t)prim * 12, ray, 0.001, tbest, t);
                     else if (lkind == ZR_PRIM_CUBE) h = cube_t(sc.cubes + (size_t)prim * 6, ray, 0.001, tbest, t);
                     else h = medium_plain_t(sc, prim, ray, 0.001, tbest, g, t);
-                } else if (LEVEL == 3 && lkind == ZR_KIND_INSTANCE) {   // a placed run of triangles: its own tree, walked right here with the mapped ray
-                    uint32_t tri = 0, nb = 0, nt = 0;
-                    h = instance_t(sc, prim, ray, 0.001, tbest, t, tri, nb, nt);
-                    if (COUNT) { c_nodes += nb; c_tri += nt; c_med--; }
-                    if (h) { tbest = t; tbest_f = __double2float_ru(t); kbest = ZR_KIND_INSTANCE | (prim << 8); ibest = tri; h = false; }
                 } else h = object_t(sc, lkind, prim, ray, 0.001, tbest, g, t);
                 if (h) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                 tested = true;
+                }
             }
             if (tested) {
                 pend_i++;
