@@ -1552,7 +1552,11 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     }
     int rc;
     if ((rc = ensure_stack_slabs(c, s))) return rc;
-    if ((rc = c->d_pool.alloc(zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS))) return rc;
+    // the slot pool, its sub-pools' rounding, and behind them the small pool the survivors of a frame's drain are moved to (zr_stream.hip: stream_compact)
+    const uint32_t drain_slots = c->st_slots / 16 / 256 * 256 + 256;
+    const size_t drain_at = zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS;
+    if ((rc = c->d_pool.alloc(drain_at + zr::stream_pool_bytes(drain_slots)))) return rc;
+    const bool use_drain = env_double("ZR_STREAM_DRAIN_POOL", 1) != 0;
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
     if (keep_going || progress) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame / a preview reduces what exists
@@ -1572,7 +1576,8 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
-                                     keep_going, &rounds, s->leaf_level, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress);
+                                     keep_going, &rounds, s->leaf_level, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress,
+                                     use_drain ? (void*)((unsigned char*)c->d_pool.p + drain_at) : nullptr, drain_slots);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));

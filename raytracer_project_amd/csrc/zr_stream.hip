@@ -705,6 +705,32 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     }
 }
 
+// THE DRAIN.  Once the last work unit has been handed out a frame lives on its longest paths: cfg5 (depth 50) spends 36 of its
+// 118 rounds on a pool that is almost empty, and a round costs 0.8 ms however few paths it carries (every EXTEND wave still
+// walks its share of the slot pool to find them).  So when no unit is left and fewer than 1/16 of the slots are active, the
+// host has the survivors MOVED to the front of a small pool of their own (all 23 state rows of a slot: a slot is self-contained,
+// its unit id travels with it) and runs the remaining rounds on that.  Which slot holds a path changes; nothing else does.
+__global__ __launch_bounds__(256) void stream_compact(StreamBuf S, StreamBuf D, unsigned int* __restrict__ counter) {
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    bool act = false;
+    if (slot < S.P) act = (S.ld2(SF_MA, slot).y & F_ACTIVE) != 0;
+    const unsigned long long bm = __ballot(act);
+    if (bm == 0ull) return;
+    const int wl = threadIdx.x & 63, lead = (int)__builtin_ctzll(bm);
+    uint32_t base = 0;
+    if (wl == lead) base = atomicAdd(counter, (unsigned int)__popcll(bm));
+    base = __shfl(base, lead, 64);
+    if (!act) return;
+    const uint32_t d = base + (uint32_t)__popcll(bm & ((1ull << wl) - 1ull));
+    if (d >= D.P) return;   // (cannot happen: the host sized D from the same count)
+#pragma unroll
+    for (int f = 0; f <= SF_MB; f++) D.st(f, d, S.ld(f, slot));   // the 23 rows in use (the 24th is spare)
+}
+__global__ __launch_bounds__(256) void stream_compact_pad(StreamBuf D, uint32_t from) {   // the slots behind the survivors: inactive
+    const uint32_t slot = from + blockIdx.x * 256 + threadIdx.x;
+    if (slot < D.P) { uint2 z; z.x = 0; z.y = 0; D.st2(SF_MA, slot, z); }
+}
+
 // one wave per pixel: lane l sums samples l, l + 64, ... in order, then a fixed xor butterfly — the order depends on
 // spp only, never on which slot produced a sample
 __global__ __launch_bounds__(256) void stream_reduce(StreamBuf B, DCamera cam, double* __restrict__ out) {
@@ -850,7 +876,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int generic, int mode, void* d_kend, void* d_cls,
-                         double* out2, unsigned long long* d_cpart, StreamProgress* progress) {
+                         double* out2, unsigned long long* d_cpart, StreamProgress* progress, void* drain_pool, uint32_t drain_slots) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     int K = n_pools < 1 ? 1 : (n_pools > ST_MAX_POOLS ? ST_MAX_POOLS : n_pools);
@@ -908,7 +934,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     }
     int rounds = K > 1 ? 1 : 0;
     int check_every = progress ? 2 : 8;
-    bool cancelled = false;
+    bool cancelled = false, drained = false;
     for (;;) {
         for (int r = 0; r < check_every; r++) {
             for (int k = K - 1; k >= 0; k--) { extend(Q[k], ov[k], streams[k]); shade(Q[k], streams[k]); }
@@ -916,7 +942,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         }
         for (int k = 0; k < K && e == hipSuccess; k++)
             e = hipMemcpyAsync(h_active + (size_t)k * W, d_ctl + (size_t)k * W, W * sizeof(unsigned int), hipMemcpyDeviceToHost, streams[k]);
-        if (progress && e == hipSuccess)   // the work-unit counters: how many samples have been started
+        if (e == hipSuccess)   // the work-unit counters: how many samples have been started
             e = hipMemcpyAsync(h_active + (size_t)ST_MAX_POOLS * W, uctl, W * sizeof(unsigned int), hipMemcpyDeviceToHost, streams[0]);
         for (int k = K - 1; k >= 0 && e == hipSuccess; k--) e = hipStreamSynchronize(streams[k]);
         if (e != hipSuccess) break;
@@ -937,6 +963,20 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
             progress->report(frac, reduced);
         }
         if (active == 0) break;
+        if (!drained && drain_pool && active * 16ull <= (unsigned long long)P && active <= (unsigned long long)drain_slots) {
+            bool units_left = false;   // shard sh has handed out every k below its counter: unit_base + k * shards + sh
+            for (int sh = 0; sh < ST_SHARDS && !units_left; sh++)
+                if ((unsigned long long)P + (unsigned long long)h_active[(size_t)ST_MAX_POOLS * W + 32 * sh] * ST_SHARDS + sh < (unsigned long long)n_units) units_left = true;
+            if (!units_left) {   // see stream_compact
+                StreamBuf D = Q[0];
+                D.pool = (double*)drain_pool; D.P = (uint32_t)((active + 255ull) / 256ull * 256ull); D.unit0 = 0;
+                unsigned int* counter = d_ctl + 4;   // a control word of pool 0 nothing else uses; zero since the frame began
+                for (int k = 0; k < K; k++) hipLaunchKernelGGL(stream_compact, dim3((Q[k].P + 255) / 256), dim3(256), 0, stream, Q[k], D, counter);
+                if (D.P > (uint32_t)active) hipLaunchKernelGGL(stream_compact_pad, dim3((D.P - (uint32_t)active + 255) / 256), dim3(256), 0, stream, D, (uint32_t)active);
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess) break;
+                Q[0] = D; K = 1; drained = true;
+            }
+        }
         check_every = active > P / 2 ? 8 : (active > P / 16 ? 4 : 2);
         if (progress && check_every > 2) check_every = 2;   // an interactive caller: report (and poll keep_going) every other round
         if (keep_going && *keep_going == 0) { cancelled = true; break; }
