@@ -1003,7 +1003,9 @@ zr_ctx* zr_create(int device_ordinal) {
         c->st_blocks = zr::stream_extend_blocks();
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
         if (over > 0) c->st_blocks = over;
-        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 32.0 * 1024 * 1024);
+        // 64 Mi slots = 12.9 GB of path state (of 288 GB): cfg3 368 ms against 392 with 32 Mi and 424 with 16 Mi — a launch that carries
+        // twice the rays walks the tree 9 % cheaper per ray — and nothing more from 96 or 128 Mi (profiles/r2_experiments_ab.txt)
+        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 64.0 * 1024 * 1024);
         // dynamic work units of shard s are handed out only by SHADE blocks with blockIdx % 64 == s (zr_stream.hip): a pool needs at
         // least 64 SHADE blocks (64 x 256 slots) or the units of the unserved shards would never be rendered
         c->st_slots = std::max<uint32_t>(64u * 256u, c->st_slots / 256 * 256);
