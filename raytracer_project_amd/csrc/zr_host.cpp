@@ -92,6 +92,7 @@ struct zr_ctx {
     DevBuf<unsigned long long> d_ctr;
     DevBuf<double> d_out;
     DevBuf<int32_t> d_tiles;
+    bool warned_fallback = false;         // the notice about a frame beyond the streaming pipeline's limits has been printed
     int variant = 2;                      // 2 streaming wavefront pipeline (default); 0 pixel-group megakernel (the fallback for frames beyond the pipeline's packing limits)
     // variant 2: slot pool and per-frame buffers
     DevBuf<unsigned char> d_pool;
@@ -1612,6 +1613,12 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going, 0, nullptr, progress);
         if (rows_done && r2 == ZR_OK) *rows_done = plan.H;
         return r2;
+    }
+    if (c->variant == 2 && !c->warned_fallback) {   // said once per context: the frame is rendered, by the slower kernel
+        c->warned_fallback = true;
+        std::fprintf(stderr, "[zr] frame outside the streaming pipeline's packing limits (max_depth %d > 250, %llu work units > 2^32, %d x %d px > 65535, "
+                             "or a scene with more than 2^24 primitives of a kind): rendered by the pixel-group kernel — same results, about six times slower\n",
+                     dc.max_depth, (unsigned long long)stream_units, plan.W, plan.H);
     }
     // one launch per frame unless the caller wants progress / cancellation, which need batch boundaries
     const bool interactive = keep_going || rows_done;
