@@ -109,6 +109,24 @@ def cpu_baseline(workload):
             "reference_at_16_threads": few, "port": port, "port_matches_reference": bool(same)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — as FRESH child processes, before this
+    process has touched the GPU (an exec or a fork after a HIP call is not allowed on this pool) — through
+    torch.distributed.run on 127.0.0.1, relay rank 0's JSON line and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env)
+    raise SystemExit(p.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,12 +141,18 @@ def main():
         print(kernel_src_sha())
         return
 
+    if args.gpus > 1 and "RANK" not in os.environ:   # started plainly, like the N = 1 case: be our own launcher
+        self_launch(args.gpus)
+
     import torch
     from raytracer_project_amd import capi, multi
 
     rank, local, world = multi.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world > 1 and not os.environ.get("ZR_BENCH_ONE_DEVICE") and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} device(s) "
+                         "(ZR_BENCH_ONE_DEVICE=1 ZR_DIST_BACKEND=gloo rehearses the N-rank path on one GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     if os.environ.get("ZR_BENCH_ONE_DEVICE"):   # rehearsal of the N > 1 path on a one-GPU box (gloo): every rank on device 0

@@ -29,14 +29,15 @@
 extern "C" {
 #endif
 
-#define ZR_ABI_VERSION 2
+#define ZR_ABI_VERSION 3
 
 enum {
     ZR_OK = 0,
     ZR_E_INVALID = -1,  /* bad argument / inconsistent scene */
     ZR_E_DEVICE = -2,   /* HIP runtime error (no device, launch failure, out of memory) */
     ZR_E_STATE = -3,    /* call order violated (e.g. render before commit) */
-    ZR_E_CANCELLED = -4 /* render_flag went false; partial results were written */
+    ZR_E_CANCELLED = -4, /* render_flag went false; partial results were written */
+    ZR_E_NOMEM = -5      /* device memory exhausted where the library could not work around it (it first shrinks its own buffers) */
 };
 
 /* ---- primitive / object kinds ------------------------------------------------------------- */
@@ -343,9 +344,12 @@ int zr_get_kernel_times(zr_ctx*, float* ms, int cap);
 /* ---- multi-GPU: the one collective of a frame, for hosts that stay C++ (no torch) ---------------------------- */
 /* One process per GPU.  Each rank renders its interleaved tiles with zr_render_device(region.tile_mod = nranks,
  * region.tile_rem = rank, region.tile_size) into a W*H*3 double frame in HBM.  zr_comm_gather_frame then packs the pixels of
- * the rank's own tiles (1/nranks of the frame), hands the packed tiles round with ONE ncclAllGather and scatters the other
- * ranks' tiles into `root`'s frame: each rank sends its share once over each xGMI link instead of pushing a whole frame of
- * mostly zeros through a ring reduce, and no arithmetic touches the pixels.  zr_comm_reduce_frame is the round-1 form: the
+ * the rank's own tiles (1/nranks of the frame) and sends them to `root`, which receives the other ranks' shares (one grouped
+ * ncclSend / ncclRecv exchange: only the root needs the frame) and scatters them into its frame: each rank's share crosses one
+ * xGMI link once instead of a whole frame of mostly zeros going through a ring reduce, and no arithmetic touches the pixels.
+ * `region` is the zr_region the rank rendered with: the exchange moves tile t from rank t % nranks, so anything but the whole
+ * frame with tile_mod = nranks and tile_rem = rank is refused (ZR_E_INVALID) rather than silently overwriting rendered pixels
+ * (ABI 3; ABI 2 took the bare tile size).  zr_comm_reduce_frame is the round-1 form: the
  * zero-initialised frames summed onto `root` in place (ncclReduce, ncclDouble, ncclSum); tiles are disjoint, so it is exact too.
  * The reference has no counterpart: it shards rows over std::threads in one address space (camera.hpp:557-573).
  * librccl.so is loaded lazily (dlopen) by these entry points only. */
@@ -354,7 +358,7 @@ typedef struct zr_comm zr_comm;
 int zr_comm_unique_id(unsigned char id[ZR_COMM_ID_BYTES]);  /* rank 0 creates it and ships it to the other ranks */
 zr_comm* zr_comm_create(zr_ctx*, int nranks, int rank, const unsigned char id[ZR_COMM_ID_BYTES]);
 int zr_comm_reduce_frame(zr_comm*, void* d_frame, size_t n_doubles, int root, void* hip_stream);
-int zr_comm_gather_frame(zr_comm*, void* d_frame, int W, int H, int tile_size /* 0 = 32 */, int root, void* hip_stream);
+int zr_comm_gather_frame(zr_comm*, void* d_frame, int W, int H, const zr_region* region, int root, void* hip_stream);
 void zr_comm_destroy(zr_comm*);
 
 /* ---- known-answer entry: world.hit(r, interval(tmin,tmax), rec) for a batch of rays ---------- */

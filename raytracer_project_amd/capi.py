@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZR_LIB") or os.path.join(_HERE, "csrc", "libzr_hip.so")
 SCENES_LIB_PATH = os.path.join(_HERE, "csrc", "libzr_scenes.so")
 
-ZR_OK, ZR_E_INVALID, ZR_E_DEVICE, ZR_E_STATE, ZR_E_CANCELLED = 0, -1, -2, -3, -4
+ZR_OK, ZR_E_INVALID, ZR_E_DEVICE, ZR_E_STATE, ZR_E_CANCELLED, ZR_E_NOMEM = 0, -1, -2, -3, -4, -5
 NO_TEXTURE = 0xFFFFFFFF
 
 
@@ -208,7 +208,7 @@ def load():
     lib.zr_comm_unique_id.argtypes = [vp]
     lib.zr_comm_create.restype = vp; lib.zr_comm_create.argtypes = [vp, i32, i32, vp]
     lib.zr_comm_reduce_frame.argtypes = [vp, vp, C.c_size_t, i32, vp]
-    lib.zr_comm_gather_frame.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.zr_comm_gather_frame.argtypes = [vp, vp, i32, i32, C.POINTER(Region), i32, vp]
     lib.zr_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib

@@ -77,8 +77,11 @@ struct DevBuf {
     int alloc(size_t count) {
         if (count == n && p) return ZR_OK;
         release();
+        if (hipMalloc((void**)&p, std::max<size_t>(sizeof(T) * count, 64)) != hipSuccess) {
+            p = nullptr; (void)hipGetLastError();
+            return fail(ZR_E_DEVICE, "out of device memory (%zu bytes requested)", sizeof(T) * count);
+        }
         n = count;
-        HIP_OK(hipMalloc((void**)&p, std::max<size_t>(sizeof(T) * count, 64)));
         return ZR_OK;
     }
 };
@@ -152,6 +155,7 @@ struct zr_scene {
     std::vector<zr_group> groups;   // runs of triangles that ZR_PRIM_GROUP objects place (small: copied)
     bool borrowed = false;        // the geometry arrays are the caller's (released after the commit)
     bool released = false;        // ... and have been released: the scene cannot be committed again without new input
+    unsigned reset_mask = 0;      // ... which geometry arrays have been given again since (SET_* bits, zr_host.cpp: GEOMETRY_SET)
     std::vector<zr_material> materials;
     std::vector<zr_texture> textures;
     HostArray<unsigned char> texels;
@@ -508,6 +512,7 @@ struct Flattener {
     // Returns the number of pair records written (at least one: a run that fits one leaf gets a pair with an empty second child).
     uint32_t emit_run(uint32_t g, uint32_t base) {
         const zr::BuildResult& rb = (*runs)[g];
+        static_assert(zr::NodeArray::zero_filled, "the id-range scans below read slots the builder never wrote: they must read as zero");
         const zr_group& grp = s.groups[g];
         // the run's triangles in the order of its leaves by ascending node id — the order index_nodes() gives a tree's leaves, so that
         // the run's 4-wide nodes (emit_run_quads, numbered by a flattener of their own) name the same indices
@@ -569,6 +574,7 @@ struct Flattener {
     // real node is (a leaf has count > 0, an inner node left = id + 1 > 0) — so the walk is two passes of prefix sums over the
     // id range, every thread on its own slice, instead of a serial recursion over two million nodes.
     void index_nodes() {
+        static_assert(zr::NodeArray::zero_filled, "the unused ids between real nodes must read as zero (neither leaf nor inner)");
         const size_t N = br.nodes.size();
         const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), N / 65536 + 1));
         struct Tally { size_t inner = 0, leaves = 0; uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
@@ -1046,42 +1052,53 @@ void zr_scene_destroy(zr_scene* s) {
     delete s;
 }
 
-#define CHECK_SCENE(s) do { if (!(s)) return fail(ZR_E_INVALID, "null scene"); (s)->committed = false; (s)->released = false; } while (0)
+// A borrowed commit drops every geometry view (`released`): the scene can be committed again only after ALL of them were given
+// again — zr_scene_set_all / zr_scene_set_all_borrowed, or each of the six geometry setters (SET_* bits).  A lone
+// zr_scene_set_materials must not re-arm the commit: it would build an empty world and return ZR_OK.
+enum { SET_SPHERES = 1, SET_TRIANGLES = 2, SET_CUBES = 4, SET_MEDIA = 8, SET_OPS = 16, SET_OBJECTS = 32, SET_ALL_GEOMETRY = 63 };
+#define CHECK_SCENE(s) do { if (!(s)) return fail(ZR_E_INVALID, "null scene"); (s)->committed = false; } while (0)
+#define GEOMETRY_SET(s, bit) do { if ((s)->released) { (s)->reset_mask |= (bit); if (((s)->reset_mask & SET_ALL_GEOMETRY) == SET_ALL_GEOMETRY) { (s)->released = false; (s)->reset_mask = 0; } } } while (0)
 
 int zr_scene_set_spheres(zr_scene* s, const double* p, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!p || !mat)) return fail(ZR_E_INVALID, "null sphere arrays");
     s->spheres.copy(p, n * 4); s->sphere_mat.copy(mat, n);
+    GEOMETRY_SET(s, SET_SPHERES);
     return ZR_OK;
 }
 int zr_scene_set_triangles(zr_scene* s, const double* v9, const double* n9, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!v9 || !n9 || !mat)) return fail(ZR_E_INVALID, "null triangle arrays");
     s->tri_v.copy(v9, n * 9); s->tri_n.copy(n9, n * 9); s->tri_mat.copy(mat, n);
+    GEOMETRY_SET(s, SET_TRIANGLES);
     return ZR_OK;
 }
 int zr_scene_set_cubes(zr_scene* s, const double* q, const uint32_t* mat, size_t n) {
     CHECK_SCENE(s);
     if (n && (!q || !mat)) return fail(ZR_E_INVALID, "null cube arrays");
     s->cubes.copy(q, n * 12); s->cube_mat.copy(mat, n);
+    GEOMETRY_SET(s, SET_CUBES);
     return ZR_OK;
 }
 int zr_scene_set_media(zr_scene* s, const zr_medium* m, size_t n) {
     CHECK_SCENE(s);
     if (n && !m) return fail(ZR_E_INVALID, "null media array");
     s->media.copy(m, n);
+    GEOMETRY_SET(s, SET_MEDIA);
     return ZR_OK;
 }
 int zr_scene_set_xform_ops(zr_scene* s, const zr_xform_op* o, size_t n) {
     CHECK_SCENE(s);
     if (n && !o) return fail(ZR_E_INVALID, "null op array");
     s->ops.copy(o, n);
+    GEOMETRY_SET(s, SET_OPS);
     return ZR_OK;
 }
 int zr_scene_set_objects(zr_scene* s, const zr_object* o, size_t n) {
     CHECK_SCENE(s);
     if (n && !o) return fail(ZR_E_INVALID, "null object array");
     s->objects.copy(o, n); s->objects_set = n > 0;
+    GEOMETRY_SET(s, SET_OBJECTS);
     return ZR_OK;
 }
 int zr_scene_set_groups(zr_scene* s, const zr_group* g, size_t n) {
@@ -1131,7 +1148,7 @@ int zr_scene_set_all_borrowed(zr_scene* s, const zr_scene_desc* d) {
     s->ops.borrow(d->ops, d->n_ops);
     s->objects.borrow(d->objects, d->n_objects); s->objects_set = d->n_objects > 0;
     s->texels.borrow((const unsigned char*)d->texels, d->texel_bytes);
-    s->borrowed = true;
+    s->borrowed = true; s->released = false; s->reset_mask = 0;
     int rc;
     if ((rc = zr_scene_set_groups(s, d->groups, d->n_groups))) return rc;
     if ((rc = zr_scene_set_materials(s, d->materials, d->n_materials))) return rc;   // the small tables are copied: render calls validate against them
@@ -1546,22 +1563,50 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     if (units > 0xFFFFFFFFull) return fail(ZR_E_INVALID, "frame too large for kernel variant 2 (pixels x spp must fit 32 bits); shard it (zr_region) or set ZR_KERNEL=0");
     // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
     // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
-    uint32_t P = c->st_slots / 64 * 64;
-    {
+    int rc;
+    if ((rc = ensure_stack_slabs(c, s))) return rc;
+    // per-sample radiance first: without it this pipeline cannot run at all (the caller falls back to the pixel-group kernel)
+    const size_t samples_n = (size_t)units * 3;
+    if (c->d_partial.n < samples_n) {
+        HIP_OK(hipStreamSynchronize(stream));
+        if (c->d_partial.alloc(samples_n) != ZR_OK) return fail(ZR_E_NOMEM, "no device memory for the per-sample radiance buffer (%zu bytes)", samples_n * sizeof(double));
+    }
+    // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
+    // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
+    const bool affine = env_double("ZR_STREAM_AFFINE", 0) != 0;   // measured: -18 % L2 requests, -14 % misses, frame time +1 % (profiles/r3_affine_ab.txt): off
+    uint32_t P = 0, unit_chunk = 0, drain_slots = 0;
+    size_t drain_at = 0;
+    for (uint32_t cap = c->st_slots;; cap /= 2) {
+        P = cap / 64 * 64;
         uint64_t want = std::max<uint64_t>(units / (uint64_t)std::max(1.0, env_double("ZR_STREAM_UNITS_PER_SLOT", 8)), 1u << 20);
         want = want / 64 * 64;
         if (want < P) P = (uint32_t)want;
         if (units < P) P = (uint32_t)((units + 63) / 64 * 64);
+        // XCD-affine hand-out of the work units (zr_stream.hip: st_unit_of): chunks of `unit_chunk` units — by default the samples of
+        // 1024 consecutive pixels of the tile-ordered list, i.e. one 32 x 32 tile — belong to one shard, hence to one XCD's L2
+        unit_chunk = 0;
+        if (affine) {
+            const uint32_t round = 64u * 256u;   // a pool is whole rounds of ST_SHARDS SHADE blocks
+            P = std::max<uint32_t>(round, P / round * round);
+            if (units < P) P = (uint32_t)((units + round - 1) / round * round);
+            uint64_t G = (uint64_t)std::max(1.0, env_double("ZR_STREAM_CHUNK_PX", 1024)) * spp;
+            G = std::min<uint64_t>(G, units / (64u * 8u));   // every shard gets at least eight chunks (small frames: smaller chunks)
+            unit_chunk = (uint32_t)std::max<uint64_t>(256, std::min<uint64_t>(G, 1u << 30));
+        }
+        // the slot pool, its sub-pools' rounding, and behind them the small pool the survivors of a frame's drain are moved to
+        // (zr_stream.hip: stream_compact).  Sized for the P this frame uses and only ever grown: a 64 x 64 test frame or a one-ray
+        // device_hit() does not reserve the 13.7 GB a 1080p frame at 512 spp wants ("Device memory")
+        drain_slots = P / 16 / 256 * 256 + 256;
+        drain_at = zr::stream_pool_bytes(P) + 65536 * ST_MAX_POOLS;
+        const size_t pool_need = drain_at + zr::stream_pool_bytes(drain_slots);
+        if (c->d_pool.n >= pool_need) break;
+        HIP_OK(hipStreamSynchronize(stream));
+        if (c->d_pool.alloc(pool_need) == ZR_OK) break;
+        // a pool that cannot be had is retried at half the size: the frame takes more rounds, the image is the same
+        if (cap <= (1u << 20)) return fail(ZR_E_NOMEM, "no device memory for a slot pool of %u paths (%zu bytes)", P, pool_need);
+        std::fprintf(stderr, "[zr] no device memory for a pool of %u path slots (%zu bytes): retrying with half\n", P, pool_need);
     }
-    int rc;
-    if ((rc = ensure_stack_slabs(c, s))) return rc;
-    // the slot pool, its sub-pools' rounding, and behind them the small pool the survivors of a frame's drain are moved to (zr_stream.hip: stream_compact)
-    const uint32_t drain_slots = c->st_slots / 16 / 256 * 256 + 256;
-    const size_t drain_at = zr::stream_pool_bytes(c->st_slots) + 65536 * ST_MAX_POOLS;
-    if ((rc = c->d_pool.alloc(drain_at + zr::stream_pool_bytes(drain_slots)))) return rc;
     const bool use_drain = env_double("ZR_STREAM_DRAIN_POOL", 1) != 0;
-    const size_t samples_n = (size_t)units * 3;
-    if (c->d_partial.n < samples_n) { if ((rc = c->d_partial.alloc(samples_n))) return rc; }
     if (keep_going || progress) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));  // a cancelled frame / a preview reduces what exists
     if (mode != 0) {
         if (c->d_kend.n < units * 2) { if ((rc = c->d_kend.alloc(units * 2))) return rc; }
@@ -1580,7 +1625,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
                                      keep_going, &rounds, s->leaf_level, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress,
-                                     use_drain ? (void*)((unsigned char*)c->d_pool.p + drain_at) : nullptr, drain_slots);
+                                     use_drain ? (void*)((unsigned char*)c->d_pool.p + drain_at) : nullptr, drain_slots, unit_chunk);
     if (e != hipSuccess) return fail(ZR_E_DEVICE, "streaming pipeline failed: %s", hipGetErrorString(e));
     c->last_rounds = (uint64_t)(rounds < 0 ? -rounds : rounds);
     HIP_OK(hipStreamSynchronize(stream));
@@ -1612,9 +1657,12 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     if (c->variant == 2 && dc.max_depth <= 250 && s->quad_ok && stream_units <= 0xFFFFFFFFull && plan.W <= 65535 && plan.H <= 65535) {
         int r2 = render_stream(c, s, dc, de, seed, plan, count, d_out, stream, keep_going, 0, nullptr, progress);
         if (rows_done && r2 == ZR_OK) *rows_done = plan.H;
-        return r2;
-    }
-    if (c->variant == 2 && !c->warned_fallback) {   // said once per context: the frame is rendered, by the slower kernel
+        if (r2 != ZR_E_NOMEM) return r2;
+        // the pipeline's buffers (24 bytes per primary sample + the slot pool) do not fit beside what else lives on the device: the
+        // pixel-group kernel below needs neither
+        std::fprintf(stderr, "[zr] %s: rendering this frame with the pixel-group kernel (same results, slower)\n", g_err.c_str());
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    } else if (c->variant == 2 && !c->warned_fallback) {   // said once per context: the frame is rendered, by the slower kernel
         c->warned_fallback = true;
         std::fprintf(stderr, "[zr] frame outside the streaming pipeline's packing limits (max_depth %d > 250, %llu work units > 2^32, %d x %d px > 65535, "
                              "or a scene with more than 2^24 primitives of a kind): rendered by the pixel-group kernel — same results, about six times slower\n",

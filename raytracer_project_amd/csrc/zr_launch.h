@@ -48,7 +48,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int leaf_level, int mode = 0, void* d_kend = nullptr,
                          void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr, StreamProgress* progress = nullptr,
-                         void* drain_pool = nullptr, uint32_t drain_slots = 0);
+                         void* drain_pool = nullptr, uint32_t drain_slots = 0, uint32_t unit_chunk = 0);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
                         void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, int leaf_level,
                         hipStream_t stream);

@@ -75,6 +75,8 @@ struct StreamBuf {
     uint32_t P, spp, n_units, n_pix;
     uint32_t unit0;           // slot k of this pool starts on unit unit0 + k
     uint32_t unit_base;       // first dynamically assigned unit (= slots of both pools)
+    uint32_t unit_chunk;      // 0: units are striped over the shards (unit_base + k * ST_SHARDS + shard); G > 0: XCD-affine hand-out, see st_unit_of
+    uint32_t shard_k0;        // affine hand-out: index in its shard's sequence of the first unit a shard deals dynamically (= slots per shard)
     uint2* kend;              // reflection / refraction split: per unit (draws, segments) the beauty path consumed
     unsigned char* cls;       // reflection / refraction split: per unit 1 = reflection, 2 = refraction, 0 = no contribution
     unsigned long long* cpart; // reflection / refraction split: per SHADE block (samples, segments, hits, draws), owned by that block
@@ -87,6 +89,27 @@ struct StreamBuf {
     __device__ __forceinline__ void st3(int f, uint32_t slot, V3 v) const { st(f, slot, v.x); st(f + 1, slot, v.y); st(f + 2, slot, v.z); }
 };
 
+
+// Which unit is the k-th of shard `shard`.
+//  striped (G = 0): unit_base + k * ST_SHARDS + shard — every shard sweeps the whole frame, one unit in ST_SHARDS.
+//  affine  (G > 0): the frame's units (pixel list in tile order x spp) are cut into chunks of G units and chunk c belongs to
+//    the shard at position c % ST_SHARDS of a round; within its chunks a shard deals consecutive units.  A shard is served by
+//    the SHADE blocks and the EXTEND waves with blockIdx % ST_SHARDS == shard, i.e. by ONE XCD class (blocks b and b + 8 share
+//    an XCD: MI355X_MICROARCH.md, workgroup dispatch), and position (shard % 8) * 8 + shard / 8 puts the eight shards of a class
+//    side by side: at any time an XCD's L2 sees the rays of ~8 neighbouring chunks (screen tiles) instead of every 64th unit of
+//    a front that spans the frame.  The image cannot depend on it: samples[unit] is written once, by whichever slot got the unit.
+__host__ __device__ inline unsigned long long st_unit_of(uint32_t G, uint32_t unit_base, uint32_t shard, unsigned long long k) {
+    if (G == 0) return (unsigned long long)unit_base + k * ST_SHARDS + shard;
+    const uint32_t k32 = (uint32_t)k, q = k32 / G, r = k32 - q * G;
+    const uint32_t pos = (shard & 7u) * (ST_SHARDS / 8u) + (shard >> 3);
+    return ((unsigned long long)q * ST_SHARDS + pos) * G + r;
+}
+// the unit slot g (index over all sub-pools) starts on
+__host__ __device__ inline unsigned long long st_first_unit(uint32_t G, uint32_t g) {
+    if (G == 0) return g;
+    const uint32_t c = g >> 8;
+    return st_unit_of(G, 0, c % ST_SHARDS, (unsigned long long)(c / ST_SHARDS) * 256u + (g & 255u));
+}
 
 // ---- begin a sample in a slot: camera ray + fresh path state --------------------------------------------
 __device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t& c_samp) {
@@ -108,7 +131,8 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= B.P) return;
     uint32_t c_samp = 0;
-    if (B.unit0 + slot < B.n_units) begin_sample(B, cam, seed, slot, B.unit0 + slot, c_samp);
+    const unsigned long long u0 = st_first_unit(B.unit_chunk, B.unit0 + slot);
+    if (u0 < (unsigned long long)B.n_units) begin_sample(B, cam, seed, slot, (uint32_t)u0, c_samp);
     else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
@@ -681,7 +705,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             k0 = __shfl(k0, (int)__builtin_ctzll(wm), 64);
             if (want_unit) {
                 const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
-                const unsigned long long u = (unsigned long long)B.unit_base + k * ST_SHARDS + shard;
+                const unsigned long long u = st_unit_of(B.unit_chunk, B.unit_base, shard, (unsigned long long)B.shard_k0 + k);
                 if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, c_samp); active_after = true; }
                 else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
             }
@@ -854,7 +878,8 @@ static StreamBuf make_buf(void* pool, uint32_t P, uint32_t spp, uint32_t n_units
                           unsigned int* ctl, unsigned int* uctl, uint32_t unit0, uint32_t unit_base) {
     StreamBuf B;
     B.pool = (double*)pool; B.pixels = pixels; B.samples = samples; B.ctl = ctl; B.uctl = uctl;
-    B.P = P; B.spp = spp; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base; B.kend = nullptr; B.cls = nullptr; B.cpart = nullptr;
+    B.P = P; B.spp = spp; B.n_units = n_units; B.n_pix = n_pix; B.unit0 = unit0; B.unit_base = unit_base; B.unit_chunk = 0; B.shard_k0 = 0;
+    B.kend = nullptr; B.cls = nullptr; B.cpart = nullptr;
     return B;
 }
 
@@ -876,11 +901,16 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          uint32_t n_pix, const uint32_t* d_pixels, double* d_samples, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks,
                          double* out, unsigned long long* gctr, bool count, hipStream_t* streams, int n_pools, hipEvent_t ev, StreamTimer* timer,
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int generic, int mode, void* d_kend, void* d_cls,
-                         double* out2, unsigned long long* d_cpart, StreamProgress* progress, void* drain_pool, uint32_t drain_slots) {
+                         double* out2, unsigned long long* d_cpart, StreamProgress* progress, void* drain_pool, uint32_t drain_slots, uint32_t unit_chunk) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     int K = n_pools < 1 ? 1 : (n_pools > ST_MAX_POOLS ? ST_MAX_POOLS : n_pools);
     while (K > 1 && P / K < 64u * 1024u) K--;
+    // affine hand-out (st_unit_of): a slot's shard is (slot / 256) % ST_SHARDS counted over ALL sub-pools, and the SHADE block that
+    // serves it must agree (blockIdx % ST_SHARDS inside its sub-pool): pool and sub-pools are whole rounds of ST_SHARDS blocks
+    const uint32_t pool_round = unit_chunk ? ST_SHARDS * 256u : 64u;
+    if (unit_chunk && P % pool_round != 0) return hipErrorInvalidValue;
+    while (K > 1 && P / K < pool_round) K--;
     StreamBuf Q[ST_MAX_POOLS];
     void* ov[ST_MAX_POOLS];
     unsigned int* uctl = d_ctl + (size_t)ST_MAX_POOLS * W;
@@ -888,8 +918,9 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         uint32_t first = 0;
         unsigned char* base = (unsigned char*)pool;
         for (int k = 0; k < K; k++) {
-            uint32_t Pk = k == K - 1 ? P - first : (P / K + 63) / 64 * 64;
+            uint32_t Pk = k == K - 1 ? P - first : (P / K + pool_round - 1) / pool_round * pool_round;
             Q[k] = make_buf(base, Pk, spp, n_units, n_pix, d_pixels, d_samples, d_ctl + (size_t)k * W, uctl, first, P);
+            Q[k].unit_chunk = unit_chunk; Q[k].shard_k0 = unit_chunk ? P / ST_SHARDS : 0u;
             Q[k].kend = (uint2*)d_kend; Q[k].cls = (unsigned char*)d_cls;
             Q[k].cpart = d_cpart ? d_cpart + ((size_t)first / 256 + (size_t)k) * 4 : nullptr;
             ov[k] = (unsigned char*)d_overflow + (size_t)k * stream_overflow_bytes(extend_blocks, ovf_levels);
@@ -934,7 +965,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     }
     int rounds = K > 1 ? 1 : 0;
     int check_every = progress ? 2 : 8;
-    bool cancelled = false, drained = false;
+    bool cancelled = false, drained = false, capped = false;
     for (;;) {
         for (int r = 0; r < check_every; r++) {
             for (int k = K - 1; k >= 0; k--) { extend(Q[k], ov[k], streams[k]); shade(Q[k], streams[k]); }
@@ -947,11 +978,22 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         for (int k = K - 1; k >= 0 && e == hipSuccess; k--) e = hipStreamSynchronize(streams[k]);
         if (e != hipSuccess) break;
         unsigned long long active = 0;
-        for (int k = 0; k < K; k++)
+        for (int k = 0; k < K; k++) {
+            if (h_active[(size_t)k * W + 2] != 0) capped = true;   // (looked at here, for every sub-pool: the drain below folds them into one)
             for (int sh = 0; sh < ST_SHARDS; sh++) active += h_active[(size_t)k * W + 16 + 32 * sh + 16];
+        }
         if (progress && active != 0) {
-            unsigned long long started = P;   // the first P units are dealt at initialisation, the rest through the sharded counters
-            for (int sh = 0; sh < ST_SHARDS; sh++) started += h_active[(size_t)ST_MAX_POOLS * W + 32 * sh];
+            unsigned long long started = 0;   // the first P units are dealt at initialisation, the rest through the sharded counters
+            if (!unit_chunk) { started = P; for (int sh = 0; sh < ST_SHARDS; sh++) started += h_active[(size_t)ST_MAX_POOLS * W + 32 * sh]; }
+            else for (int sh = 0; sh < ST_SHARDS; sh++) {   // affine: of a shard's sequence, the units that exist (a shard's last chunks may lie beyond the frame)
+                const unsigned long long k_sh = (unsigned long long)(P / ST_SHARDS) + h_active[(size_t)ST_MAX_POOLS * W + 32 * sh];
+                const uint32_t pos = ((uint32_t)sh & 7u) * (ST_SHARDS / 8u) + ((uint32_t)sh >> 3);
+                const unsigned long long full = k_sh / unit_chunk, part = k_sh % unit_chunk;
+                for (unsigned long long q = 0; q <= full; q++) {
+                    const unsigned long long c0 = (q * ST_SHARDS + pos) * unit_chunk, len = q < full ? unit_chunk : part;
+                    if (c0 < n_units) started += c0 + len <= n_units ? len : n_units - c0;
+                }
+            }
             if (started > n_units) started = n_units;
             const double frac = started > active ? (double)(started - active) / (double)n_units : 0.0;
             bool reduced = false;
@@ -966,7 +1008,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         if (!drained && drain_pool && active * 16ull <= (unsigned long long)P && active <= (unsigned long long)drain_slots) {
             bool units_left = false;   // shard sh has handed out every k below its counter: unit_base + k * shards + sh
             for (int sh = 0; sh < ST_SHARDS && !units_left; sh++)
-                if ((unsigned long long)P + (unsigned long long)h_active[(size_t)ST_MAX_POOLS * W + 32 * sh] * ST_SHARDS + sh < (unsigned long long)n_units) units_left = true;
+                if (st_unit_of(unit_chunk, P, (uint32_t)sh, (unsigned long long)(unit_chunk ? P / ST_SHARDS : 0u) + h_active[(size_t)ST_MAX_POOLS * W + 32 * sh]) < (unsigned long long)n_units) units_left = true;
             if (!units_left) {   // see stream_compact
                 StreamBuf D = Q[0];
                 D.pool = (double*)drain_pool; D.P = (uint32_t)((active + 255ull) / 256ull * 256ull); D.unit0 = 0;
@@ -983,7 +1025,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         if (rounds > (1 << 22)) { e = hipErrorLaunchFailure; break; }
     }
     if (e != hipSuccess) return e;
-    for (int k = 0; k < K; k++) if (h_active[(size_t)k * W + 2] != 0) return hipErrorLaunchFailure;  // an EXTEND wave hit its iteration cap
+    if (capped) return hipErrorLaunchFailure;  // an EXTEND wave of some sub-pool hit its iteration cap: its rays were abandoned mid-walk
     const StreamBuf& A = Q[0];
     if (timer) timer->begin(stream, 3);
     if (d_cpart) hipLaunchKernelGGL(stream_sum_counters, dim3(1), dim3(256), 0, stream, d_cpart, cpart_blocks, gctr);

@@ -1,7 +1,7 @@
 """Pixel-tile sharding of one frame across the GPUs of a node: one process per GPU, scene replicated,
 interleaved 32x32 tiles (tile t -> rank t % world), and ONE collective per frame (torch.distributed backend
-"nccl" = RCCL over xGMI): every rank packs the pixels of ITS tiles (1/world of the frame) and one all-gather hands
-the packed tiles round; rank 0 scatters them into the frame.  Each rank therefore sends 1/world of the double3 frame
+"nccl" = RCCL over xGMI): every rank packs the pixels of ITS tiles (1/world of the frame) and one gather hands
+the packed tiles to rank 0, which scatters them into the frame.  Each rank therefore sends 1/world of the double3 frame
 over each of its xGMI links (6.2 MB at 1080p and 8 ranks) instead of pushing the whole 49.8 MB frame — 7/8 of it
 zeros — through a ring sum-reduce (`exchange="reduce"`, the round-1 form, is kept for comparison).
 
@@ -79,8 +79,10 @@ def owned_pixels(height, width, world, device, tile=TILE):
 
 
 def gather_frame(acc, world, dst=0, tile=TILE):
-    """The one collective of a frame: all-gather of every rank's packed tiles (1/world of the frame each, padded to the
-    largest share), scattered into `acc` on rank `dst`.  Pure data movement: bit-exact."""
+    """The one collective of a frame: a GATHER of every rank's packed tiles (1/world of the frame each, padded to the
+    largest share) onto rank `dst`, which scatters them into `acc`.  Only `dst` needs the frame, so only `dst` receives:
+    each share crosses one xGMI link once (round 2 used an all-gather, which also delivered 7 shares to each of the 7 ranks
+    that dropped them).  Pure data movement: bit-exact."""
     if world <= 1:
         return acc
     import torch
@@ -94,19 +96,19 @@ def gather_frame(acc, world, dst=0, tile=TILE):
     flat = frame.view(-1, 3)
     packed = torch.zeros((m, 3), dtype=frame.dtype, device=frame.device)
     packed[:own[rank].numel()] = flat[own[rank]]
-    everyone = torch.empty((world * m, 3), dtype=frame.dtype, device=frame.device)
-    dist.all_gather_into_tensor(everyone, packed)
+    shares = [torch.empty((m, 3), dtype=frame.dtype, device=frame.device) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, shares, dst=dst)
     if rank == dst:
         for r in range(world):
             if r != rank:
-                flat[own[r]] = everyone[r * m:r * m + own[r].numel()]
+                flat[own[r]] = shares[r][:own[r].numel()]
         if staged:
             acc.copy_(frame)
     return acc
 
 
 def exchange_frame(acc, world, dst=0, tile=TILE):
-    """packed-tile all-gather by default; ZR_MULTI_EXCHANGE=reduce selects the whole-frame sum-reduce"""
+    """packed-tile gather onto `dst` by default; ZR_MULTI_EXCHANGE=reduce selects the whole-frame sum-reduce"""
     if os.environ.get("ZR_MULTI_EXCHANGE", "gather") == "reduce":
         return reduce_frame(acc, world, dst)
     return gather_frame(acc, world, dst, tile)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(lib, name), f"libzr_hip.so does not export {name}"
     assert sorted(capi.CAPI_SYMBOLS) == declared, "capi.CAPI_SYMBOLS out of sync with include/zr_capi.h"
-    assert lib.zr_abi_version() == 2
+    assert lib.zr_abi_version() == 3
 
 
 def test_ctypes_mirrors_match_c_structs(built):

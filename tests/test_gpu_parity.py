@@ -712,6 +712,7 @@ def test_cxx_host_collective_single_rank(ctx):
     lazy librccl.so binding, communicator creation on the context's device and an in-place ncclReduce of doubles."""
     import ctypes as C
     import torch
+    from raytracer_project_amd import capi
     lib = ctx.lib
     uid = (C.c_ubyte * 128)()
     assert lib.zr_comm_unique_id(uid) == 0, lib.zr_last_error()
@@ -722,11 +723,17 @@ def test_cxx_host_collective_single_rank(ctx):
     assert lib.zr_comm_reduce_frame(comm, C.c_void_p(frame.data_ptr()), frame.numel(), 0, None) == 0, lib.zr_last_error()
     torch.cuda.synchronize()
     assert torch.equal(frame, want)
-    # the packed-tile exchange (pack own tiles -> ncclAllGather -> scatter on the root): with one rank the frame comes back as it was
+    # the packed-tile exchange (pack own tiles -> send to the root -> scatter there): with one rank the frame comes back as it was
     for tile in (0, 20):   # default 32-pixel tiles; 20-pixel tiles leave clipped tiles at both edges of the 64 x 48 frame
-        assert lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), 64, 48, tile, 0, None) == 0, lib.zr_last_error()
+        reg = capi.Region(0, 0, 0, 0, tile, 0, 0, 0)
+        assert lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), 64, 48, C.byref(reg), 0, None) == 0, lib.zr_last_error()
         torch.cuda.synchronize()
         assert torch.equal(frame, want)
+    # a region that is not the partition the exchange assumes is refused, not "gathered"
+    bad = capi.Region(0, 0, 0, 0, 32, 2, 1, 0)
+    assert lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), 64, 48, C.byref(bad), 0, None) == capi.ZR_E_INVALID
+    part = capi.Region(8, 8, 16, 16, 32, 0, 0, 0)
+    assert lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), 64, 48, C.byref(part), 0, None) == capi.ZR_E_INVALID
     lib.zr_comm_destroy(comm)
 
 
@@ -763,7 +770,9 @@ own = multi.owned_pixels(H, W, world, full.device, T)
 for mode in ("gather", "reduce"):
     frame = torch.zeros_like(full)
     frame.view(-1, 3)[own[rank]] = full.view(-1, 3)[own[rank]]
-    if mode == "gather": rc = lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), W, H, T, 0, None)
+    if mode == "gather":
+        reg = multi.tile_region(capi, rank, world, T)
+        rc = lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), W, H, C.byref(reg), 0, None)
     else: rc = lib.zr_comm_reduce_frame(comm, C.c_void_p(frame.data_ptr()), frame.numel(), 0, None)
     assert rc == 0, lib.zr_last_error()
     torch.cuda.synchronize()
@@ -777,3 +786,38 @@ print("rank", rank, "ok")
         p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                             "--master-port", "29547", f], env=dict(os.environ, ZR_ROOT=ROOT), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.count("ok") == 2, p.stdout + p.stderr
+
+
+def test_affine_unit_handout_is_bit_identical(ctx):
+    """ZR_STREAM_AFFINE=1 (work units dealt to the shards in screen-space chunks, zr_stream.hip st_unit_of) changes which slot
+    renders which sample and nothing else: the frame equals the striped hand-out's bit for bit, whole and sharded."""
+    from raytracer_project_amd import capi
+    ds = demo_scene("mix0")
+    sc = gpu_scene(ctx, "mix0")
+    cam = ds.camera.copy(); cam.samples_per_pixel = 24
+    outs = {}
+    for aff in ("0", "1"):
+        os.environ["ZR_STREAM_AFFINE"] = aff
+        try:
+            outs[aff] = (sc.render(cam, ds.env, ds.seed), sc.render(cam, ds.env, ds.seed, capi.Region(0, 0, 0, 0, 16, 3, 1, 0)))
+        finally:
+            del os.environ["ZR_STREAM_AFFINE"]
+    assert np.array_equal(outs["0"][0], outs["1"][0])
+    assert np.array_equal(outs["0"][1], outs["1"][1])
+    assert float(outs["1"][0].sum()) > 0
+
+
+def test_released_scene_is_not_rearmed_by_a_table_setter(ctx):
+    """After a borrowed commit the geometry views are gone: zr_scene_set_materials alone must not make the scene committable
+    again (it would build an empty world); giving every geometry array again does."""
+    import ctypes as C
+    from raytracer_project_amd import capi
+    ds = demo_scene("cfg1")
+    lib = ctx.lib
+    s = lib.zr_scene_create(ctx._c)
+    assert lib.zr_scene_set_all_borrowed(s, C.byref(ds.desc)) == 0 and lib.zr_scene_commit(s) == 0, lib.zr_last_error()
+    assert lib.zr_scene_commit(s) == capi.ZR_E_STATE
+    assert lib.zr_scene_set_materials(s, ds.desc.materials, ds.desc.n_materials) == 0
+    assert lib.zr_scene_commit(s) == capi.ZR_E_STATE, "a table setter re-armed a released scene"
+    assert lib.zr_scene_set_all(s, C.byref(ds.desc)) == 0 and lib.zr_scene_commit(s) == 0, lib.zr_last_error()
+    lib.zr_scene_destroy(s)
