@@ -256,6 +256,10 @@ int zr_scene_stats(const zr_scene*, uint64_t out[4]);
  * walking the 4-wide tree (the recursion depth of bvh_node::hit, bvh.hpp:46-54, has no bound in the reference; here the
  * per-wave spill slabs are sized from this number, so no scene can overrun them); 0 = not committed */
 uint32_t zr_scene_traversal_stack(const zr_scene*);
+/* which builder made the committed tree: "host (binned SAH)" (zr_bvh.cpp) or "device (PLOC)" (zr_build.hip).  The tree is
+ * built on the device for worlds of at least ZR_BVH_DEVICE_MIN world-list entries; ZR_BVH_BUILD=device|host forces one.  Replaces
+ * bvh_node's constructor (/root/reference/bvh.hpp:11-44), which the reference runs on every render restart (main.cpp:1492-1500). */
+const char* zr_scene_builder(const zr_scene*);
 
 /* ---- render: replaces camera::render's sample loop (camera.hpp:236-248, 404-579) ----------- */
 /* Fills out_rgb[(j*W+i)*3 + c] (host memory, W*H*3 doubles, row 0 = top, mean over spp — the layout of

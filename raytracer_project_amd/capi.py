@@ -157,7 +157,7 @@ CAPI_SYMBOLS = [
     "zr_abi_version", "zr_last_error", "zr_create", "zr_destroy", "zr_scene_create", "zr_scene_destroy",
     "zr_scene_set_spheres", "zr_scene_set_triangles", "zr_scene_set_cubes", "zr_scene_set_media",
     "zr_scene_set_xform_ops", "zr_scene_set_objects", "zr_scene_set_groups", "zr_scene_set_materials", "zr_scene_set_textures",
-    "zr_scene_set_all", "zr_scene_set_all_borrowed", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
+    "zr_scene_set_all", "zr_scene_set_all_borrowed", "zr_scene_commit", "zr_scene_stats", "zr_scene_traversal_stack", "zr_scene_builder", "zr_render", "zr_render_device", "zr_render_aov", "zr_render_passes", "zr_trace_paths", "zr_post_process", "zr_analyze_frame", "zr_get_counters",
     "zr_get_kernel_times", "zr_trace", "zr_kat_scatter", "zr_kat_texture", "zr_kat_background", "zr_kat_camera_rays", "zr_comm_unique_id", "zr_comm_create", "zr_comm_reduce_frame", "zr_comm_gather_frame", "zr_comm_destroy",
 ]
 
@@ -191,6 +191,7 @@ def load():
     lib.zr_scene_commit.argtypes = [vp]
     lib.zr_scene_stats.argtypes = [vp, C.POINTER(u64 * 4)]
     lib.zr_scene_traversal_stack.argtypes = [vp]; lib.zr_scene_traversal_stack.restype = C.c_uint32
+    lib.zr_scene_builder.argtypes = [vp]; lib.zr_scene_builder.restype = C.c_char_p
     lib.zr_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp, vp]
     lib.zr_render_device.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(Env), u64, C.POINTER(Region), i32, vp, vp]
     lib.zr_render_aov.argtypes = [vp, vp, C.POINTER(Camera), u64, C.POINTER(Region), C.POINTER(AovParams), vp, vp, vp]
@@ -378,7 +379,7 @@ class Scene:
         out = (C.c_uint64 * 4)()
         _check(self.lib.zr_scene_stats(self._s, C.byref(out)))
         return {"bvh_pairs": out[0], "bvh_depth": out[1], "objects": out[2], "device_bytes": out[3],
-                "traversal_stack": int(self.lib.zr_scene_traversal_stack(self._s))}
+                "traversal_stack": int(self.lib.zr_scene_traversal_stack(self._s)), "builder": self.lib.zr_scene_builder(self._s).decode()}
 
     def render(self, camera, env, seed, region=None, count=False, out=None):
         h, w = camera.image_height, camera.image_width

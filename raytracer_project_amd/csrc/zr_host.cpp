@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "../../include/zr_capi.h"
+#include "zr_build.h"
 #include "zr_bvh.h"
 #include "zr_device_types.h"
 #include "zr_launch.h"
@@ -62,6 +64,11 @@ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (hi 
 template <class T>
 struct DevBuf {
     T* p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~DevBuf() { release(); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
     int upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
@@ -177,6 +184,7 @@ struct zr_scene {
     int leaf_level = 2;           // EXTEND build: 0 bare triangles / spheres only, 1 + bare and placed cubes and unwrapped media, 2 everything
     uint32_t stack_demand = 0;    // worst-case entries on an EXTEND lane's traversal stack (Flattener::stack_demand)
     uint64_t stats[4] = {0, 0, 0, 0};
+    const char* builder = "";   // which builder made the committed tree (zr_scene_builder)
 };
 
 namespace {
@@ -246,6 +254,47 @@ inline float f_up(double x) {
     float f = (float)x;
     if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
     return std::nextafterf(f, std::numeric_limits<float>::infinity());
+}
+
+// what a world-list entry becomes in the tree: its leaf kind, and whether the host stores it "baked" (0 as is, 1 baked triangle,
+// 2 material-only chain, 3 baked sphere, 4 placed cube) — see Flattener::put_baked_triangle / put_baked_sphere / put_pcube
+inline void classify_object(const zr_scene& s, const zr_object& o, bool bake, uint32_t& kind, uint8_t& baked) {
+    kind = o.chain_count ? ZR_KIND_WRAPPED : o.type;
+    baked = 0;
+    if (o.type == ZR_PRIM_GROUP) { kind = ZR_KIND_INSTANCE; return; }   // placed as one object, whatever its chain
+    if (!bake || o.chain_count == 0) return;
+    if (o.type == ZR_PRIM_TRIANGLE) {   // see Flattener::put_baked_triangle
+        bool ok = true;
+        for (uint32_t q = 0; q < o.chain_count; q++) if (s.ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
+        if (ok) { baked = 1; kind = ZR_PRIM_TRIANGLE; }
+    }
+    if (o.type == ZR_PRIM_SPHERE) {   // see Flattener::put_baked_sphere
+        bool ok = true, moved = false; uint32_t mat = s.sphere_mat[o.index];
+        for (int q = (int)o.chain_count - 1; q >= 0 && ok; q--) {
+            const zr_xform_op& op = s.ops[o.chain_first + q];
+            if (op.kind == ZR_OP_SCALE) { ok = op.a[0] > 0 && op.a[0] == op.a[1] && op.a[1] == op.a[2]; moved = true; }
+            else if (op.kind == ZR_OP_TRANSLATE) moved = true;
+            else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
+            else ok = false;
+        }
+        if (ok && moved && mat < 0x7FFFFFFFu) { baked = 3; kind = ZR_PRIM_SPHERE; }
+    }
+    if (o.type == ZR_PRIM_CUBE) {   // see Flattener::put_pcube: [translate] or [translate, rotate_y], outermost first
+        int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
+        for (uint32_t q = 0; q < o.chain_count && ok; q++) {
+            const uint32_t kd = s.ops[o.chain_first + q].kind;
+            if (kd == ZR_OP_MATERIAL) continue;
+            if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
+            else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
+            else ok = false;
+        }
+        if (ok && pat >= 1) { baked = 4; kind = ZR_KIND_PCUBE; }
+    }
+    if (!baked && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
+        bool only_material = true;
+        for (uint32_t q = 0; q < o.chain_count; q++) if (s.ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
+        if (only_material) { baked = 2; kind = o.type; }
+    }
 }
 
 int validate(const zr_scene& s, const std::vector<zr_object>& objs) {
@@ -977,6 +1026,290 @@ double env_double(const char* name, double dflt) {
     return v && *v ? std::atof(v) : dflt;
 }
 
+struct CommitSummary {   // what the shared end of a commit needs to know about the tree either builder produced
+    zr::NodeF root{}; bool quant_ok = true;
+    size_t n_pairs = 0, n_quads = 0, n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0, n_insts = 0, kept_closed = 0;
+    bool plain_media = true;
+    uint32_t stack_demand = 0; int quad_depth = 0, max_depth = 0, max_leaf = 4;
+    const char* builder = "";
+};
+// the tables every scene has (ops, materials, textures), the DScene the kernels receive, the EXTEND build the world needs
+int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
+    int rc;
+    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", cs.n_quads, cs.kept_closed);
+    s->quad_ok = cs.quant_ok && cs.n_quads < (1u << 31) && cs.max_leaf <= 16 && cs.n_sph < (1u << 24) && cs.n_tri < (1u << 24) && cs.n_cube < (1u << 24) &&
+                 cs.n_media < (1u << 24) && cs.n_wrapped < (1u << 24) && cs.n_pcube < (1u << 24) && cs.n_insts < (1u << 24);
+    if ((rc = s->d_ops.upload(s->ops.data(), s->ops.size()))) return rc;
+    {
+        // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
+        // texture tree, or a bump map) -> the kernels compute those hit-record fields only then
+        std::vector<zr_material> mats = s->materials;
+        auto tex_uses_uv = [&](uint32_t id) {
+            std::vector<uint32_t> todo{id}; int guard = 0;
+            while (!todo.empty() && guard++ < 4096) {
+                uint32_t t = todo.back(); todo.pop_back();
+                if (t >= s->textures.size()) continue;
+                const zr_texture& tx = s->textures[t];
+                if (tx.kind >= ZR_TEX_IMAGE_U8) return true;
+                if (tx.kind == ZR_TEX_CHECKER) { todo.push_back(tx.odd); todo.push_back(tx.even); }
+            }
+            return guard >= 4096;
+        };
+        for (zr_material& m : mats) m.pad_ = (m.bump_tex != ZR_NO_TEXTURE || (m.kind != ZR_MAT_DIELECTRIC && tex_uses_uv(m.tex))) ? 1u : 0u;
+        if ((rc = s->d_mats.upload(mats))) return rc;
+    }
+    if ((rc = s->d_texs.upload(s->textures))) return rc;
+    if ((rc = s->d_texels.upload(s->texels.data(), s->texels.size()))) return rc;
+
+    zr::DScene& d = s->ds;
+    d.nodes = s->d_nodes.p; d.quads = s->d_quads.p;
+    d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
+    d.tri_v = s->d_tri_v.p; d.tri_s = s->d_tri_s.p;
+    d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
+    d.pcubes = s->d_pcubes.p; d.pcube_mat = s->d_pcube_mat.p;
+    d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.insts = s->d_insts.p; d.ops = s->d_ops.p;
+    d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
+    d.n_mats = (uint32_t)s->materials.size();
+    d.mat_kinds = 0;
+    for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
+    d.root = cs.root;
+    {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
+        if (cs.n_insts) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
+        else if (cs.n_wrapped || !cs.plain_media) s->leaf_level = 2;
+        else if (cs.n_cube || cs.n_pcube || cs.n_media) s->leaf_level = 1;
+        else s->leaf_level = 0;
+        const int force = (int)env_double("ZR_EXTEND_LEVEL", -1);
+        if (force > s->leaf_level && force <= 3) s->leaf_level = force;
+    }
+    s->stack_demand = cs.stack_demand;
+    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", cs.quad_depth, s->stack_demand);
+    s->stats[0] = cs.n_pairs; s->stats[1] = (uint64_t)cs.max_depth; s->stats[2] = n_objs;
+    s->stats[3] = cs.n_pairs * sizeof(zr::NodePair) + cs.n_quads * sizeof(zr::NodeQ) + (cs.n_sph * 4 + cs.n_tri * (ZR_TRI_STRIDE + 20) + cs.n_cube * 6 + cs.n_pcube * 12) * 8 +
+                  (cs.n_sph + cs.n_cube) * 4 + s->texels.size();
+    s->builder = cs.builder;
+    s->committed = true;
+    if (s->borrowed) {   // the caller's arrays are not read again: forget them (a second commit needs a new zr_scene_set_*)
+        s->spheres.drop(); s->sphere_mat.drop(); s->tri_v.drop(); s->tri_n.drop(); s->tri_mat.drop(); s->cubes.drop(); s->cube_mat.drop();
+        s->media.drop(); s->ops.drop(); s->objects.drop(); s->texels.drop(); s->objects_set = false; s->borrowed = false; s->released = true;
+    }
+    return ZR_OK;
+}
+
+
+// ---- the commit with the tree built ON THE DEVICE (zr_build.hip) ------------------------------------------------------------------
+// The scene's arrays go to the device as they are; boxes, Morton keys, sort, PLOC merging, leaf collapse, the 4-wide quantised
+// nodes, the pair records and the primitive records in leaf order are all produced there.  The host classifies the world-list
+// entries (a pass over 16-byte records), finishes the few compound objects (media, wrapped objects: each drags inner primitives
+// behind the leaf ranges) and sizes the final arrays.  ZR_E_STATE from here means "this input is for the host builder" (a tree
+// deeper than the traversal stack, coordinates beyond 1e18): the caller falls back.
+constexpr int ZR_FALLBACK_HOST = 1;
+int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_stats, CommitSummary& cs) {
+    auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_phase = now_s();
+    auto phase = [&](const char* what) { if (commit_stats) { const double t = now_s(); std::fprintf(stderr, "[zr] commit(device): %-22s %.1f ms\n", what, (t - t_phase) * 1e3); t_phase = t; } };
+    const uint32_t n = (uint32_t)objs.size();
+    hipStream_t st = s->ctx->stream;
+    int rc;
+    // 1. classification + array sizes
+    std::vector<uint8_t> code(n);
+    const bool bake = env_double("ZR_BAKE_TRIANGLES", 1) != 0;
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const int T = n < 65536 ? 1 : (int)std::max(1u, std::min(16u, hw));
+        std::vector<std::array<uint32_t, 8>> part((size_t)T, std::array<uint32_t, 8>{});
+        auto work = [&](int t, size_t k0, size_t k1) {
+            std::array<uint32_t, 8> c{};
+            for (size_t k = k0; k < k1; k++) { uint32_t kind; uint8_t bk; classify_object(*s, objs[k], bake, kind, bk); code[k] = (uint8_t)(kind | (bk << 4)); c[kind & 7]++; }
+            part[(size_t)t] = c;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t, (size_t)n * t / T, (size_t)n * (t + 1) / T);
+        work(0, 0, (size_t)n / T);
+        for (auto& x : th) x.join();
+        for (auto& c : part) for (int k = 0; k < 8; k++) cnt[k] += c[k];
+    }
+    size_t x_sph = 0, x_tri = 0, x_cube = 0, x_media = 0;   // primitives inside media and wrapper chains: behind the leaf ranges
+    auto count_inner = [&](uint32_t type, uint32_t idx, auto&& self) -> void {
+        if (type == ZR_PRIM_SPHERE) x_sph++; else if (type == ZR_PRIM_TRIANGLE) x_tri++; else if (type == ZR_PRIM_CUBE) x_cube++;
+        else { x_media++; self(s->media[idx].boundary_type, s->media[idx].boundary_index, self); }
+    };
+    if (cnt[ZR_PRIM_MEDIUM] + cnt[ZR_KIND_WRAPPED])
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t kind = code[k] & 7u;
+            if (kind == ZR_PRIM_MEDIUM) count_inner(s->media[objs[k].index].boundary_type, s->media[objs[k].index].boundary_index, count_inner);
+            else if (kind == ZR_KIND_WRAPPED) count_inner(objs[k].type, objs[k].index, count_inner);
+        }
+    size_t group_tris = 0;
+    for (const zr_group& g : s->groups) group_tris += g.triangle_count;
+    const size_t n_sph = cnt[ZR_PRIM_SPHERE] + x_sph, n_tri = cnt[ZR_PRIM_TRIANGLE] + group_tris + x_tri, n_cube = cnt[ZR_PRIM_CUBE] + x_cube;
+    const size_t n_pcube = cnt[ZR_KIND_PCUBE], n_media = cnt[ZR_PRIM_MEDIUM] + x_media, n_wrapped = cnt[ZR_KIND_WRAPPED], n_insts = cnt[ZR_KIND_INSTANCE];
+    phase("classify");
+    // 2. the scene as given -> device (freed with this call), the final primitive arrays allocated
+    DevBuf<double> r_sph, r_tri_v, r_tri_n, r_cubes, r_gbox;
+    DevBuf<uint32_t> r_sph_mat, r_tri_mat, r_cube_mat, d_inst_group, d_run_demand, d_run_root, d_run_qroot;
+    DevBuf<zr_medium> r_media; DevBuf<zr_object> r_objs; DevBuf<uint8_t> r_code;
+    if ((rc = r_sph.upload(s->spheres.data(), s->spheres.size())) || (rc = r_sph_mat.upload(s->sphere_mat.data(), s->sphere_mat.size())) ||
+        (rc = r_tri_v.upload(s->tri_v.data(), s->tri_v.size())) || (rc = r_tri_n.upload(s->tri_n.data(), s->tri_n.size())) ||
+        (rc = r_tri_mat.upload(s->tri_mat.data(), s->tri_mat.size())) || (rc = r_cubes.upload(s->cubes.data(), s->cubes.size())) ||
+        (rc = r_cube_mat.upload(s->cube_mat.data(), s->cube_mat.size())) || (rc = r_media.upload(s->media.data(), s->media.size())) ||
+        (rc = s->d_ops.upload(s->ops.data(), s->ops.size())) || (rc = r_objs.upload(objs)) || (rc = r_code.upload(code))) return rc;
+    if ((rc = s->d_spheres.alloc(n_sph * 4)) || (rc = s->d_sphere_mat.alloc(n_sph)) || (rc = s->d_tri_v.alloc(n_tri * ZR_TRI_STRIDE)) || (rc = s->d_tri_s.alloc(n_tri * 20)) ||
+        (rc = s->d_cubes.alloc(n_cube * 6)) || (rc = s->d_cube_mat.alloc(n_cube)) || (rc = s->d_pcubes.alloc(n_pcube * 12)) || (rc = s->d_pcube_mat.alloc(n_pcube)) ||
+        (rc = s->d_insts.alloc(n_insts)) || (rc = d_inst_group.alloc(n_insts))) return rc;
+    phase("upload as given");
+    zr::BuildSceneIn in;
+    in.spheres = r_sph.p; in.sphere_mat = r_sph_mat.p; in.tri_v = r_tri_v.p; in.tri_n = r_tri_n.p; in.tri_mat = r_tri_mat.p;
+    in.cubes = r_cubes.p; in.cube_mat = r_cube_mat.p; in.media = r_media.p; in.ops = s->d_ops.p;
+    zr::BuildParams bp;
+    bp.ct = (float)env_double("ZR_BVH_COST_TRAVERSE", 1.0);
+    const double ck[8] = {env_double("ZR_BVH_COST_SPHERE", 1.0), env_double("ZR_BVH_COST_TRI", 1.5), env_double("ZR_BVH_COST_CUBE", 1.0),
+                          env_double("ZR_BVH_COST_MEDIUM", 3.0), env_double("ZR_BVH_COST_WRAPPED", 3.0), env_double("ZR_BVH_COST_PCUBE", 1.5),
+                          env_double("ZR_BVH_COST_GROUP", 16.0), 1};
+    for (int k = 0; k < 8; k++) bp.ck[k] = (float)ck[k];
+    bp.max_leaf = (int)env_double("ZR_BVH_MAX_LEAF", 4);
+    const int big = (int)env_double("ZR_BVH_MAX_LEAF_BIG", 1);
+    const int leaf_cap[8] = {0, 0, big, big, big, big, 1, 0};
+    for (int k = 0; k < 8; k++) bp.leaf_cap[k] = leaf_cap[k];
+    bp.open_ratio = (float)env_double("ZR_BVH_OPEN_RATIO", 1.25);
+    bp.radius = (int)env_double("ZR_BVH_PLOC_RADIUS", 16);
+    zr::BuildPrimOut out;
+    out.spheres = s->d_spheres.p; out.sphere_mat = s->d_sphere_mat.p; out.tri_v = s->d_tri_v.p; out.tri_s = s->d_tri_s.p;
+    out.cubes = s->d_cubes.p; out.cube_mat = s->d_cube_mat.p; out.pcubes = s->d_pcubes.p; out.pcube_mat = s->d_pcube_mat.p;
+    out.insts = s->d_insts.p; out.inst_group = d_inst_group.p;
+    auto builder = std::make_shared<zr::DeviceBuilder>(st);
+    auto build_fail = [&](hipError_t e) {
+        if (e == hipErrorInvalidValue) { std::fprintf(stderr, "[zr] device BVH build: %s\n", builder->error()); return (int)ZR_FALLBACK_HOST; }
+        return fail(ZR_E_DEVICE, "device BVH build failed: %s (%s)", hipGetErrorString(e), builder->error());
+    };
+    // 3. the groups' trees (two-level BVH: one tree per shared run of triangles, in its own space)
+    const size_t ng = s->groups.size();
+    std::vector<zr::BuiltTree> runs(ng);
+    std::vector<double> gbox(ng * 6);
+    std::vector<uint32_t> run_demand(ng), run_tri_base(ng);
+    {
+        size_t at = cnt[ZR_PRIM_TRIANGLE];
+        for (size_t g = 0; g < ng; g++) {
+            const zr_group& grp = s->groups[g];
+            run_tri_base[g] = (uint32_t)at; at += grp.triangle_count;
+            zr::BuildPrimOut go = out;
+            go.base[ZR_PRIM_TRIANGLE] = run_tri_base[g];
+            hipError_t e = builder->build(in, nullptr, nullptr, grp.first_triangle, grp.triangle_count, bp, true, go, nullptr, ZR_STACK_DEPTH - 2, false, runs[g]);
+            if (e != hipSuccess) return build_fail(e);
+            for (int k = 0; k < 6; k++) gbox[g * 6 + k] = runs[g].box[k];
+            run_demand[g] = runs[g].demand;
+        }
+    }
+    if (ng) { if ((rc = r_gbox.upload(gbox)) || (rc = d_run_demand.upload(run_demand))) return rc; in.group_box = r_gbox.p; }
+    phase("groups' trees");
+    // 4. the world's tree
+    zr::BuiltTree world;
+    world.want_boxes = std::getenv("ZR_BUILD_CHECK") != nullptr;
+    {
+        hipError_t e = builder->build(in, r_objs.p, r_code.p, 0, n, bp, false, out, ng ? d_run_demand.p : nullptr, ZR_STACK_DEPTH - 2, commit_stats, world);
+        if (e != hipSuccess) return build_fail(e);
+    }
+    if (commit_stats)
+        std::fprintf(stderr, "[zr] device build: boxes+keys %.2f, sort %.2f, PLOC %.2f (%u iterations), order %.2f, 4-wide %.2f, pairs %.2f, emit %.2f ms; depth %u, %u pairs, %u quads\n",
+                     world.ms[0], world.ms[1], world.ms[2], world.ploc_iterations, world.ms[3], world.ms[4], world.ms[5], world.ms[6], world.depth, world.n_pairs, world.n_quads);
+    if (world.want_boxes) {   // self-check: every object's device box must contain the box the host's Boxer computes for it
+        std::vector<zr::BuildBox> gb(ng);
+        for (size_t g = 0; g < ng; g++) for (int k = 0; k < 3; k++) { gb[g].lo[k] = gbox[g * 6 + k]; gb[g].hi[k] = gbox[g * 6 + 3 + k]; }
+        Boxer boxer{*s, &gb};
+        size_t bad = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            const zr::BuildBox hb = boxer.chain(objs[k].type, objs[k].index, objs[k].chain_first, objs[k].chain_count);
+            const float* d = &world.dbg_boxes[(size_t)k * 8];
+            bool ok = true;
+            for (int a = 0; a < 3; a++) if (!((double)d[a] <= hb.lo[a]) || !((double)d[4 + a] >= hb.hi[a])) ok = false;
+            if (!ok && bad++ < 8)
+                std::fprintf(stderr, "[zr] BUILD_CHECK: object %u (type %u, chain %u): device box [%g %g %g | %g %g %g] does not contain the host's [%g %g %g | %g %g %g]\n", k, objs[k].type,
+                             objs[k].chain_count, d[0], d[1], d[2], d[4], d[5], d[6], hb.lo[0], hb.lo[1], hb.lo[2], hb.hi[0], hb.hi[1], hb.hi[2]);
+        }
+        if (bad) return fail(ZR_E_DEVICE, "ZR_BUILD_CHECK: %zu of %u object boxes computed on the device do not contain the host's", bad, n);
+    }
+    for (int k = 0; k < 8; k++)
+        if (world.cnt[k] != cnt[k]) return fail(ZR_E_DEVICE, "device BVH build: %u leaf primitives of kind %d, expected %u (internal error)", world.cnt[k], k, cnt[k]);
+    phase("world tree");
+    // 5. the scene's node arrays at their exact sizes: the world's records first, then every group's
+    size_t n_pairs = world.n_pairs, n_quads = world.n_quads;
+    std::vector<uint32_t> run_root(ng), run_qroot(ng);
+    for (size_t g = 0; g < ng; g++) { run_root[g] = (uint32_t)n_pairs; run_qroot[g] = (uint32_t)n_quads; n_pairs += runs[g].n_pairs; n_quads += runs[g].n_quads; }
+    if ((rc = s->d_nodes.alloc(n_pairs)) || (rc = s->d_quads.alloc(n_quads))) return rc;
+    {
+        hipError_t e = builder->relocate(world, s->d_nodes.p, 0, s->d_quads.p, 0);
+        for (size_t g = 0; g < ng && e == hipSuccess; g++) e = builder->relocate(runs[g], s->d_nodes.p, run_root[g], s->d_quads.p, run_qroot[g]);
+        if (e == hipSuccess && n_insts) {
+            if ((rc = d_run_root.upload(run_root)) || (rc = d_run_qroot.upload(run_qroot))) return rc;
+            e = builder->patch_instances(s->d_insts.p, d_inst_group.p, (uint32_t)n_insts, d_run_root.p, d_run_qroot.p);
+        }
+        if (e != hipSuccess) return fail(ZR_E_DEVICE, "device BVH build: %s", hipGetErrorString(e));
+    }
+    // 6. compound objects on the host: a medium's boundary, the object inside a wrapper chain (Flattener's own routines, on arrays
+    // whose untouched pages cost nothing; only what they wrote is uploaded)
+    bool plain_media = true;
+    if ((rc = s->d_media.alloc(n_media)) || (rc = s->d_wrapped.alloc(n_wrapped))) return rc;
+    if (n_media + n_wrapped) {
+        static const zr::BuildResult no_tree;
+        Flattener fl{*s, objs, no_tree};
+        fl.spheres.allocate(n_sph * 4); fl.sphere_mat.allocate(n_sph);
+        fl.tri_v.allocate(n_tri * ZR_TRI_STRIDE); fl.tri_s.allocate(n_tri * 20);
+        fl.cubes.allocate(n_cube * 6); fl.cube_mat.allocate(n_cube);
+        fl.media.allocate(n_media); fl.wrapped.allocate(n_wrapped);
+        fl.n_sph = cnt[ZR_PRIM_SPHERE]; fl.n_tri = cnt[ZR_PRIM_TRIANGLE] + group_tris; fl.n_cube = cnt[ZR_PRIM_CUBE]; fl.n_media = cnt[ZR_PRIM_MEDIUM];
+        const size_t b_sph = fl.n_sph, b_tri = fl.n_tri, b_cube = fl.n_cube;
+        std::vector<std::pair<uint32_t, uint32_t>> todo;   // (index in its kind's array, object): leaf order, media before wrapped objects
+        for (int pass = 0; pass < 2; pass++) {
+            todo.clear();
+            for (size_t k = 0; k + 1 < world.compound.size(); k += 2) {
+                const uint32_t oi = world.compound[k], di = world.compound[k + 1];
+                if (((code[oi] & 7u) == ZR_PRIM_MEDIUM) == (pass == 0)) todo.emplace_back(di, oi);
+            }
+            std::sort(todo.begin(), todo.end());
+            for (const auto& [di, oi] : todo) {
+                const zr_object& o = objs[oi];
+                if (pass == 0) fl.put_medium(di, o.index);
+                else {
+                    zr::DWrapped w{};
+                    w.type = o.type; w.chain_first = o.chain_first; w.chain_count = o.chain_count;
+                    w.index = fl.append_inner(o.type, o.index);
+                    fl.wrapped[di] = w;
+                }
+            }
+        }
+        if (fl.n_sph != n_sph || fl.n_tri != n_tri || fl.n_cube != n_cube || fl.n_media != n_media)
+            return fail(ZR_E_DEVICE, "device BVH build: compound objects do not add up (internal error)");
+        for (size_t k = 0; k < n_media; k++) if (fl.media[k].chain_count != 0) plain_media = false;
+        auto up = [&](void* dst, const void* src, size_t bytes) -> int { if (bytes) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return ZR_OK; };
+        if ((rc = up(s->d_spheres.p + b_sph * 4, &fl.spheres[b_sph * 4], (n_sph - b_sph) * 32)) || (rc = up(s->d_sphere_mat.p + b_sph, &fl.sphere_mat[b_sph], (n_sph - b_sph) * 4)) ||
+            (rc = up(s->d_tri_v.p + b_tri * ZR_TRI_STRIDE, &fl.tri_v[b_tri * ZR_TRI_STRIDE], (n_tri - b_tri) * ZR_TRI_STRIDE * 8)) ||
+            (rc = up(s->d_tri_s.p + b_tri * 20, &fl.tri_s[b_tri * 20], (n_tri - b_tri) * 160)) ||
+            (rc = up(s->d_cubes.p + b_cube * 6, &fl.cubes[b_cube * 6], (n_cube - b_cube) * 48)) || (rc = up(s->d_cube_mat.p + b_cube, &fl.cube_mat[b_cube], (n_cube - b_cube) * 4)) ||
+            (rc = up(s->d_media.p, fl.media.data(), n_media * sizeof(zr::DMedium))) || (rc = up(s->d_wrapped.p, fl.wrapped.data(), n_wrapped * sizeof(zr::DWrapped)))) return rc;
+        HIP_OK(hipStreamSynchronize(st));   // (the staging arrays die with this block)
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    phase("node arrays + compound");
+    cs.root = world.root; cs.quant_ok = world.quant_ok;
+    for (const zr::BuiltTree& r : runs) cs.quant_ok = cs.quant_ok && r.quant_ok;
+    cs.n_pairs = n_pairs; cs.n_quads = n_quads; cs.n_sph = n_sph; cs.n_tri = n_tri; cs.n_cube = n_cube; cs.n_pcube = n_pcube;
+    cs.n_media = n_media; cs.n_wrapped = n_wrapped; cs.n_insts = n_insts; cs.plain_media = plain_media;
+    cs.stack_demand = world.demand; cs.quad_depth = (int)world.quad_depth; cs.max_depth = (int)world.depth; cs.max_leaf = bp.max_leaf;
+    cs.builder = "device (PLOC)";
+    {   // the scratch arena, the trees' local records and the as-given copies: freed off the caller's clock
+        struct Trash { std::shared_ptr<zr::DeviceBuilder> b; DevBuf<double> a0, a1, a2, a3, a4; DevBuf<uint32_t> u0, u1, u2, u3, u4, u5, u6; DevBuf<zr_medium> m; DevBuf<zr_object> o; DevBuf<uint8_t> c; int device; };
+        auto t = std::make_shared<Trash>();
+        t->device = s->ctx->device;
+        t->b = std::move(builder);
+        std::swap(t->a0, r_sph); std::swap(t->a1, r_tri_v); std::swap(t->a2, r_tri_n); std::swap(t->a3, r_cubes); std::swap(t->a4, r_gbox);
+        std::swap(t->u0, r_sph_mat); std::swap(t->u1, r_tri_mat); std::swap(t->u2, r_cube_mat); std::swap(t->u3, d_inst_group); std::swap(t->u4, d_run_demand);
+        std::swap(t->u5, d_run_root); std::swap(t->u6, d_run_qroot); std::swap(t->m, r_media); std::swap(t->o, r_objs); std::swap(t->c, r_code);
+        try { std::thread([t]() mutable { (void)hipSetDevice(t->device); t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
+    }
+    phase("release");
+    return ZR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1184,6 +1517,19 @@ int zr_scene_commit(zr_scene* s) {
     if (rc) return rc;
     phase("world list + validate");
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
+    {   // which builder.  ZR_BVH_BUILD=device | host forces one; otherwise worlds of at least ZR_BVH_DEVICE_MIN entries are built
+        // on the device (a small world is built faster by the host than a few dozen kernel launches take)
+        const char* bm = std::getenv("ZR_BVH_BUILD");
+        const bool force_dev = bm && std::strcmp(bm, "device") == 0, force_host = bm && std::strcmp(bm, "host") == 0;
+        const bool use_dev = !force_host && !objs.empty() && objs.size() < (1u << 30) && (force_dev || (double)objs.size() >= env_double("ZR_BVH_DEVICE_MIN", 1e18));
+        if (use_dev) {
+            CommitSummary cs;
+            rc = commit_device(s, objs, commit_stats, cs);
+            if (rc == ZR_OK) return finish_commit(s, cs, objs.size());
+            if (rc != ZR_FALLBACK_HOST) return rc;
+            phase("device build refused");
+        }
+    }
 
     // two-level BVH: every group of triangles gets a tree of its own, in its own space, once — however many objects place it
     std::vector<zr::BuildResult> runs(s->groups.size());
@@ -1220,40 +1566,7 @@ int zr_scene_commit(zr_scene* s) {
             for (size_t k = k0; k < k1; k++) {
             const zr_object& o = objs[k];
             boxes[k] = boxer.chain(o.type, o.index, o.chain_first, o.chain_count);
-            kinds[k] = o.chain_count ? ZR_KIND_WRAPPED : o.type;
-            if (o.type == ZR_PRIM_GROUP) kinds[k] = ZR_KIND_INSTANCE;   // placed as one object, whatever its chain
-            if (bake && o.type == ZR_PRIM_TRIANGLE && o.chain_count > 0) {   // see Flattener::append_baked_triangle
-                bool ok = true;
-                for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind == ZR_OP_SCALE) ok = false;
-                if (ok) { baked[k] = 1; kinds[k] = ZR_PRIM_TRIANGLE; }
-            }
-            if (bake && o.type == ZR_PRIM_SPHERE && o.chain_count > 0) {   // see Flattener::append_baked_sphere
-                bool ok = true, moved = false; uint32_t mat = s->sphere_mat[o.index];
-                for (int q = (int)o.chain_count - 1; q >= 0 && ok; q--) {
-                    const zr_xform_op& op = s->ops[o.chain_first + q];
-                    if (op.kind == ZR_OP_SCALE) { ok = op.a[0] > 0 && op.a[0] == op.a[1] && op.a[1] == op.a[2]; moved = true; }
-                    else if (op.kind == ZR_OP_TRANSLATE) moved = true;
-                    else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
-                    else ok = false;
-                }
-                if (ok && moved && mat < 0x7FFFFFFFu) { baked[k] = 3; kinds[k] = ZR_PRIM_SPHERE; }
-            }
-            if (bake && o.type == ZR_PRIM_CUBE && o.chain_count > 0) {   // see Flattener::append_pcube: [translate] or [translate, rotate_y], outermost first
-                int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
-                for (uint32_t q = 0; q < o.chain_count && ok; q++) {
-                    const uint32_t kd = s->ops[o.chain_first + q].kind;
-                    if (kd == ZR_OP_MATERIAL) continue;
-                    if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
-                    else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
-                    else ok = false;
-                }
-                if (ok && pat >= 1) { baked[k] = 4; kinds[k] = ZR_KIND_PCUBE; }
-            }
-            if (bake && !baked[k] && o.chain_count > 0 && (o.type == ZR_PRIM_SPHERE || o.type == ZR_PRIM_CUBE)) {
-                bool only_material = true;
-                for (uint32_t q = 0; q < o.chain_count; q++) if (s->ops[o.chain_first + q].kind != ZR_OP_MATERIAL) only_material = false;
-                if (only_material) { baked[k] = 2; kinds[k] = o.type; }
-            }
+            classify_object(*s, o, bake, kinds[k], baked[k]);
             for (int a = 0; a < 3; a++)
                 if (!std::isfinite(boxes[k].lo[a]) || !std::isfinite(boxes[k].hi[a])) { size_t want = (size_t)-1; bad_box.compare_exchange_strong(want, k); }
         }
@@ -1322,63 +1635,15 @@ int zr_scene_commit(zr_scene* s) {
         fl.after_primitives(); if (uploader.joinable()) uploader.join();
     }
     if (up_rc != ZR_OK) return fail(up_rc, "%s", up_err.c_str());
-    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide nodes: %zu quantised (64 B) + FP32 root; %zu children kept closed for the grid\n", fl.quads.size(), fl.n_kept_closed);
-    s->quad_ok = fl.quant_ok && fl.quads.size() < (1u << 31) && max_leaf <= 16 && fl.sphere_mat.size() < (1u << 24) && fl.tri_s.size() / 20 < (1u << 24) && fl.cube_mat.size() < (1u << 24) &&
-                 fl.media.size() < (1u << 24) && fl.wrapped.size() < (1u << 24) && fl.pcube_mat.size() < (1u << 24) && fl.insts.size() < (1u << 24);
-    if ((rc = s->d_ops.upload(s->ops.data(), s->ops.size()))) return rc;
-    {
-        // zr_material::pad_ on the device copy: the material reads u/v/tangent (image texture anywhere in its
-        // texture tree, or a bump map) -> the kernels compute those hit-record fields only then
-        std::vector<zr_material> mats = s->materials;
-        auto tex_uses_uv = [&](uint32_t id) {
-            std::vector<uint32_t> todo{id}; int guard = 0;
-            while (!todo.empty() && guard++ < 4096) {
-                uint32_t t = todo.back(); todo.pop_back();
-                if (t >= s->textures.size()) continue;
-                const zr_texture& tx = s->textures[t];
-                if (tx.kind >= ZR_TEX_IMAGE_U8) return true;
-                if (tx.kind == ZR_TEX_CHECKER) { todo.push_back(tx.odd); todo.push_back(tx.even); }
-            }
-            return guard >= 4096;
-        };
-        for (zr_material& m : mats) m.pad_ = (m.bump_tex != ZR_NO_TEXTURE || (m.kind != ZR_MAT_DIELECTRIC && tex_uses_uv(m.tex))) ? 1u : 0u;
-        if ((rc = s->d_mats.upload(mats))) return rc;
-    }
-    if ((rc = s->d_texs.upload(s->textures))) return rc;
-    if ((rc = s->d_texels.upload(s->texels.data(), s->texels.size()))) return rc;
-
-    zr::DScene& d = s->ds;
-    d.nodes = s->d_nodes.p; d.quads = s->d_quads.p;
-    d.spheres = s->d_spheres.p; d.sphere_mat = s->d_sphere_mat.p;
-    d.tri_v = s->d_tri_v.p; d.tri_s = s->d_tri_s.p;
-    d.cubes = s->d_cubes.p; d.cube_mat = s->d_cube_mat.p;
-    d.pcubes = s->d_pcubes.p; d.pcube_mat = s->d_pcube_mat.p;
-    d.media = s->d_media.p; d.wrapped = s->d_wrapped.p; d.insts = s->d_insts.p; d.ops = s->d_ops.p;
-    d.mats = s->d_mats.p; d.texs = s->d_texs.p; d.texels = s->d_texels.p;
-    d.n_mats = (uint32_t)s->materials.size();
-    d.mat_kinds = 0;
-    for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
-    d.root = fl.root;
-    {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
-        bool plain_media = true;   // media whose boundary is an unwrapped sphere or cube
-        for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) plain_media = false;
-        if (!fl.insts.empty()) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
-        else if (!fl.wrapped.empty() || !plain_media) s->leaf_level = 2;
-        else if (!fl.cubes.empty() || !fl.pcube_mat.empty() || !fl.media.empty()) s->leaf_level = 1;
-        else s->leaf_level = 0;
-        const int force = (int)env_double("ZR_EXTEND_LEVEL", -1);
-        if (force > s->leaf_level && force <= 3) s->leaf_level = force;
-    }
-    s->stack_demand = fl.stack_demand();
-    if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", fl.quad_depth, s->stack_demand);
-    s->stats[0] = fl.pairs.size(); s->stats[1] = (uint64_t)br.max_depth; s->stats[2] = objs.size();
-    s->stats[3] = fl.pairs.size() * sizeof(zr::NodePair) + fl.quads.size() * sizeof(zr::NodeQ) + (fl.spheres.size() + fl.tri_v.size() + fl.tri_s.size() + fl.cubes.size() + fl.pcubes.size()) * 8 +
-                  (fl.sphere_mat.size() + fl.cube_mat.size()) * 4 + s->texels.size();
-    s->committed = true;
-    if (s->borrowed) {   // the caller's arrays are not read again: forget them (a second commit needs a new zr_scene_set_*)
-        s->spheres.drop(); s->sphere_mat.drop(); s->tri_v.drop(); s->tri_n.drop(); s->tri_mat.drop(); s->cubes.drop(); s->cube_mat.drop();
-        s->media.drop(); s->ops.drop(); s->objects.drop(); s->texels.drop(); s->objects_set = false; s->borrowed = false; s->released = true;
-    }
+    CommitSummary cs;
+    cs.root = fl.root; cs.quant_ok = fl.quant_ok; cs.n_pairs = fl.pairs.size(); cs.n_quads = fl.quads.size();
+    cs.n_sph = fl.sphere_mat.size(); cs.n_tri = fl.tri_s.size() / 20; cs.n_cube = fl.cube_mat.size(); cs.n_pcube = fl.pcube_mat.size();
+    cs.n_media = fl.media.size(); cs.n_wrapped = fl.wrapped.size(); cs.n_insts = fl.insts.size();
+    cs.plain_media = true;   // media whose boundary is an unwrapped sphere or cube
+    for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) cs.plain_media = false;
+    cs.stack_demand = fl.stack_demand(); cs.quad_depth = fl.quad_depth; cs.max_depth = br.max_depth; cs.max_leaf = max_leaf; cs.kept_closed = fl.n_kept_closed;
+    cs.builder = "host (binned SAH)";
+    if ((rc = finish_commit(s, cs, objs.size()))) return rc;
     phase("upload");
     {   // unmapping half a gigabyte of staging arrays takes tens of milliseconds: not on the caller's clock
         struct Trash { std::shared_ptr<Flattener> fl; zr::BuildResult br; std::vector<zr::BuildBox> boxes; std::vector<zr_object> objs;
@@ -1399,6 +1664,7 @@ int zr_scene_stats(const zr_scene* s, uint64_t out[4]) {
 }
 
 uint32_t zr_scene_traversal_stack(const zr_scene* s) { return s && s->committed ? s->stack_demand : 0u; }
+const char* zr_scene_builder(const zr_scene* s) { return s && s->committed ? s->builder : ""; }
 
 }  // extern "C"
 
