@@ -21,6 +21,7 @@
 #include <atomic>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/zr_capi.h"
@@ -115,6 +116,7 @@ struct zr_ctx {
     DevBuf<unsigned char> d_st_overflow;
     uint32_t st_ovf_levels = 0;           // levels per lane the spill slabs of d_st_overflow hold
     int st_blocks = 0;
+    int fused_blocks = 0;                 // persistent grid of the fused small-scene kernel (0: not asked yet)
     uint32_t st_slots = 0;
     int st_pools = -1;                    // sub-pools staggered on separate streams: 1 = one pool, -1 = auto
     hipEvent_t st_event = nullptr;
@@ -183,6 +185,7 @@ struct zr_scene {
     zr::DScene ds{};
     int leaf_level = 2;           // EXTEND build: 0 bare triangles / spheres only, 1 + bare and placed cubes and unwrapped media, 2 everything
     uint32_t stack_demand = 0;    // worst-case entries on an EXTEND lane's traversal stack (Flattener::stack_demand)
+    size_t leaf_objects = 0;      // leaf objects of the world's tree (all kinds): small worlds render through the fused kernel
     uint64_t stats[4] = {0, 0, 0, 0};
     const char* builder = "";   // which builder made the committed tree (zr_scene_builder)
 };
@@ -1031,6 +1034,7 @@ struct CommitSummary {   // what the shared end of a commit needs to know about 
     size_t n_pairs = 0, n_quads = 0, n_sph = 0, n_tri = 0, n_cube = 0, n_pcube = 0, n_media = 0, n_wrapped = 0, n_insts = 0, kept_closed = 0;
     bool plain_media = true;
     uint32_t stack_demand = 0; int quad_depth = 0, max_depth = 0, max_leaf = 4;
+    uint32_t leaf_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // leaf objects per kind
     const char* builder = "";
 };
 // the tables every scene has (ops, materials, textures), the DScene the kernels receive, the EXTEND build the world needs
@@ -1073,6 +1077,8 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
     d.mat_kinds = 0;
     for (const zr_material& m : s->materials) d.mat_kinds |= 1u << m.kind;
     d.root = cs.root;
+    s->leaf_objects = 0;
+    for (int k = 0; k < 8; k++) { d.leaf_cnt[k] = cs.leaf_cnt[k]; s->leaf_objects += cs.leaf_cnt[k]; }
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         if (cs.n_insts) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
         else if (cs.n_wrapped || !cs.plain_media) s->leaf_level = 2;
@@ -1145,15 +1151,32 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     const size_t n_sph = cnt[ZR_PRIM_SPHERE] + x_sph, n_tri = cnt[ZR_PRIM_TRIANGLE] + group_tris + x_tri, n_cube = cnt[ZR_PRIM_CUBE] + x_cube;
     const size_t n_pcube = cnt[ZR_KIND_PCUBE], n_media = cnt[ZR_PRIM_MEDIUM] + x_media, n_wrapped = cnt[ZR_KIND_WRAPPED], n_insts = cnt[ZR_KIND_INSTANCE];
     phase("classify");
-    // 2. the scene as given -> device (freed with this call), the final primitive arrays allocated
+    // 2. the scene as given -> device (freed with this call), the final primitive arrays allocated.  The large arrays are pinned for the
+    // copy (hipHostRegister: 2.4 ms per 160 MB on the GPU box, then 57 GB/s instead of the ~10 GB/s of a first pageable copy,
+    // profiles/r3_affine_ab.txt) and travel asynchronously on the build's stream, under the classification above... and below
     DevBuf<double> r_sph, r_tri_v, r_tri_n, r_cubes, r_gbox;
     DevBuf<uint32_t> r_sph_mat, r_tri_mat, r_cube_mat, d_inst_group, d_run_demand, d_run_root, d_run_qroot;
     DevBuf<zr_medium> r_media; DevBuf<zr_object> r_objs; DevBuf<uint8_t> r_code;
-    if ((rc = r_sph.upload(s->spheres.data(), s->spheres.size())) || (rc = r_sph_mat.upload(s->sphere_mat.data(), s->sphere_mat.size())) ||
-        (rc = r_tri_v.upload(s->tri_v.data(), s->tri_v.size())) || (rc = r_tri_n.upload(s->tri_n.data(), s->tri_n.size())) ||
-        (rc = r_tri_mat.upload(s->tri_mat.data(), s->tri_mat.size())) || (rc = r_cubes.upload(s->cubes.data(), s->cubes.size())) ||
-        (rc = r_cube_mat.upload(s->cube_mat.data(), s->cube_mat.size())) || (rc = r_media.upload(s->media.data(), s->media.size())) ||
-        (rc = s->d_ops.upload(s->ops.data(), s->ops.size())) || (rc = r_objs.upload(objs)) || (rc = r_code.upload(code))) return rc;
+    struct Pinned { std::vector<void*> p; ~Pinned() { for (void* q : p) (void)hipHostUnregister(q); } } pinned;
+    auto send = [&](auto& buf, const auto* src, size_t count) -> int {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(src)>>;
+        int r = buf.alloc(count);
+        if (r || count == 0) return r;
+        const size_t bytes = count * sizeof(T);
+        if (bytes >= (4u << 20) && hipHostRegister((void*)src, bytes, hipHostRegisterDefault) == hipSuccess) {
+            pinned.p.push_back((void*)src);
+            HIP_OK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));
+        } else {
+            (void)hipGetLastError();
+            HIP_OK(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+        }
+        return ZR_OK;
+    };
+    if ((rc = send(r_tri_v, s->tri_v.data(), s->tri_v.size())) || (rc = send(r_tri_n, s->tri_n.data(), s->tri_n.size())) ||
+        (rc = send(r_objs, objs.data(), objs.size())) || (rc = send(r_tri_mat, s->tri_mat.data(), s->tri_mat.size())) ||
+        (rc = send(r_sph, s->spheres.data(), s->spheres.size())) || (rc = send(r_sph_mat, s->sphere_mat.data(), s->sphere_mat.size())) ||
+        (rc = send(r_cubes, s->cubes.data(), s->cubes.size())) || (rc = send(r_cube_mat, s->cube_mat.data(), s->cube_mat.size())) ||
+        (rc = send(r_media, s->media.data(), s->media.size())) || (rc = s->d_ops.upload(s->ops.data(), s->ops.size())) || (rc = send(r_code, code.data(), code.size()))) return rc;
     if ((rc = s->d_spheres.alloc(n_sph * 4)) || (rc = s->d_sphere_mat.alloc(n_sph)) || (rc = s->d_tri_v.alloc(n_tri * ZR_TRI_STRIDE)) || (rc = s->d_tri_s.alloc(n_tri * 20)) ||
         (rc = s->d_cubes.alloc(n_cube * 6)) || (rc = s->d_cube_mat.alloc(n_cube)) || (rc = s->d_pcubes.alloc(n_pcube * 12)) || (rc = s->d_pcube_mat.alloc(n_pcube)) ||
         (rc = s->d_insts.alloc(n_insts)) || (rc = d_inst_group.alloc(n_insts))) return rc;
@@ -1295,6 +1318,7 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     cs.n_pairs = n_pairs; cs.n_quads = n_quads; cs.n_sph = n_sph; cs.n_tri = n_tri; cs.n_cube = n_cube; cs.n_pcube = n_pcube;
     cs.n_media = n_media; cs.n_wrapped = n_wrapped; cs.n_insts = n_insts; cs.plain_media = plain_media;
     cs.stack_demand = world.demand; cs.quad_depth = (int)world.quad_depth; cs.max_depth = (int)world.depth; cs.max_leaf = bp.max_leaf;
+    for (int k = 0; k < 8; k++) cs.leaf_cnt[k] = cnt[k];
     cs.builder = "device (PLOC)";
     {   // the scratch arena, the trees' local records and the as-given copies: freed off the caller's clock
         struct Trash { std::shared_ptr<zr::DeviceBuilder> b; DevBuf<double> a0, a1, a2, a3, a4; DevBuf<uint32_t> u0, u1, u2, u3, u4, u5, u6; DevBuf<zr_medium> m; DevBuf<zr_object> o; DevBuf<uint8_t> c; int device; };
@@ -1642,6 +1666,7 @@ int zr_scene_commit(zr_scene* s) {
     cs.plain_media = true;   // media whose boundary is an unwrapped sphere or cube
     for (size_t k = 0; k < fl.media.size(); k++) if (fl.media[k].chain_count != 0) cs.plain_media = false;
     cs.stack_demand = fl.stack_demand(); cs.quad_depth = fl.quad_depth; cs.max_depth = br.max_depth; cs.max_leaf = max_leaf; cs.kept_closed = fl.n_kept_closed;
+    for (int k = 0; k < 8; k++) cs.leaf_cnt[k] = fl.cnt[k];
     cs.builder = "host (binned SAH)";
     if ((rc = finish_commit(s, cs, objs.size()))) return rc;
     phase("upload");
@@ -1830,13 +1855,28 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
     // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
     int rc;
-    if ((rc = ensure_stack_slabs(c, s))) return rc;
     // per-sample radiance first: without it this pipeline cannot run at all (the caller falls back to the pixel-group kernel)
     const size_t samples_n = (size_t)units * 3;
     if (c->d_partial.n < samples_n) {
         HIP_OK(hipStreamSynchronize(stream));
         if (c->d_partial.alloc(samples_n) != ZR_OK) return fail(ZR_E_NOMEM, "no device memory for the per-sample radiance buffer (%zu bytes)", samples_n * sizeof(double));
     }
+    // A world of a handful of objects is rendered by the FUSED kernel (zr_stream.hip: fused_render): every object tested per
+    // segment, the path in registers, no tree, no slot pool.  Testing all objects costs time in proportion to their number, the
+    // pipeline about the same per segment whatever the scene: the switch-over is ZR_FUSED_MAX objects.  Callers that poll
+    // (cancellation, live preview) and the split passes stay on the pipeline, which has round boundaries to poll at.
+    if (mode == 0 && !keep_going && !progress && s->leaf_level <= 2 && s->leaf_objects > 0 && (double)s->leaf_objects <= env_double("ZR_FUSED_MAX", 16) &&
+        env_double("ZR_FUSED", 1) != 0) {
+        if (c->fused_blocks == 0) c->fused_blocks = zr::fused_blocks();
+        HostTimer ftimer(c);
+        hipError_t fe = zr::fused_render_frame(s->ds, dc, de, seed, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p, c->fused_blocks, d_out, c->d_ctr.p, count != 0,
+                                               s->leaf_level <= 1 ? 1 : 2, stream, &ftimer);
+        if (fe != hipSuccess) return fail(ZR_E_DEVICE, "fused small-scene kernel failed: %s", hipGetErrorString(fe));
+        c->last_rounds = 1;
+        HIP_OK(hipStreamSynchronize(stream));
+        return ZR_OK;
+    }
+    if ((rc = ensure_stack_slabs(c, s))) return rc;
     // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
     // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
     const bool affine = env_double("ZR_STREAM_AFFINE", 0) != 0;   // measured: -18 % L2 requests, -14 % misses, frame time +1 % (profiles/r3_affine_ab.txt): off

@@ -49,6 +49,9 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int leaf_level, int mode = 0, void* d_kend = nullptr,
                          void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr, StreamProgress* progress = nullptr,
                          void* drain_pool = nullptr, uint32_t drain_slots = 0, uint32_t unit_chunk = 0);
+int fused_blocks();
+hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
+                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
                         void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, int leaf_level,
                         hipStream_t stream);

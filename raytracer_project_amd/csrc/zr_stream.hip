@@ -729,6 +729,170 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     }
 }
 
+// ---- FUSED small-scene path ---------------------------------------------------------------------------------------------------
+// A world of a few dozen objects (cfg5: seven placed cubes, a sphere, a medium) needs no tree and no pool: streaming its paths
+// through EXTEND and SHADE moved 405 bytes of path state per segment through HBM for nine objects (profiles/r2_cfg5_traffic.json:
+// 979 GB per frame), and the frame's 486 ms were those round trips.  Here a lane keeps its whole path in registers and tests
+// EVERY leaf object of the world each segment — the loop counter is wave-uniform, so the objects' records arrive through scalar
+// loads, once per wave — then shades the winner in place; a lane whose path ends writes the sample and starts the next work unit
+// (persistent threads with regeneration: the intersection loop always runs under a full exec mask, only the material branch
+// diverges).  HBM sees 24 bytes per SAMPLE (samples[unit], reduced by stream_reduce as in the pipeline): the kernel is bound by
+// FP64 vector issue.  Arithmetic and decisions are the pipeline's (the same zr_device.h routines in the same order), so a frame
+// agrees with the pipeline's to the last bits of FMA contraction.
+// Work units: waves reserve chunks of ST_FUSED_CHUNK consecutive units (one atomic per chunk, ST_SHARDS interleaved counters), so
+// that the 64 lanes of a wave share a pixel; every wave reaches the exit: it leaves when its lanes are idle and every shard is dry.
+#ifndef ST_FUSED_CHUNK
+#define ST_FUSED_CHUNK 256
+#endif
+#ifndef ST_FUSED_WAVES
+#define ST_FUSED_WAVES 2
+#endif
+struct FusedBuf {
+    const uint32_t* pixels; double* samples; unsigned int* uctl;   // uctl[32 s]: chunk counter of shard s
+    uint32_t spp, n_units;
+};
+template <int LEVEL, bool COUNT>
+__device__ __forceinline__ void brute_hit(const DScene& sc, const Ray& ray, const Rng& g, double& tbest, uint32_t& kbest, uint32_t& ibest, uint32_t* cn) {
+    const double INF = __builtin_huge_val();
+    tbest = INF; kbest = 0xFFFFFFFFu; ibest = 0;
+    double t;
+    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_SPHERE]; i++)
+        if (sphere_t(sc.spheres + (size_t)i * 4, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_SPHERE; ibest = i; }
+    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_TRIANGLE]; i++)
+        if (triangle_t(sc.tri_v + (size_t)i * ZR_TRI_STRIDE, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_TRIANGLE; ibest = i; }
+    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_CUBE]; i++)
+        if (cube_t(sc.cubes + (size_t)i * 6, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_CUBE; ibest = i; }
+    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_PCUBE]; i++)
+        if (pcube_t(sc.pcubes + (size_t)i * 12, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_KIND_PCUBE; ibest = i; }
+    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_MEDIUM]; i++) {
+        const bool h = LEVEL == 1 ? medium_plain_t(sc, i, ray, 0.001, tbest, g, t) : medium_t(sc, i, ray, 0.001, tbest, g, t);
+        if (h) { tbest = t; kbest = ZR_PRIM_MEDIUM; ibest = i; }
+    }
+    if (LEVEL >= 2)
+        for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_WRAPPED]; i++)
+            if (object_t(sc, ZR_KIND_WRAPPED, i, ray, 0.001, tbest, g, t)) { tbest = t; kbest = ZR_KIND_WRAPPED; ibest = i; }
+    if (COUNT) {
+        cn[0] += sc.leaf_cnt[ZR_PRIM_SPHERE]; cn[1] += sc.leaf_cnt[ZR_PRIM_TRIANGLE]; cn[2] += sc.leaf_cnt[ZR_PRIM_CUBE] + sc.leaf_cnt[ZR_KIND_PCUBE]; cn[3] += sc.leaf_cnt[ZR_PRIM_MEDIUM];
+        if (LEVEL >= 2)
+            for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_WRAPPED]; i++) {
+                const uint32_t kk = sc.wrapped[i].type;
+                if (kk == ZR_PRIM_SPHERE) cn[0]++; else if (kk == ZR_PRIM_TRIANGLE) cn[1]++; else if (kk == ZR_PRIM_CUBE) cn[2]++; else cn[3]++;
+            }
+    }
+}
+
+template <int LEVEL, bool COUNT>
+__global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, DCamera cam, DEnv env, uint64_t seed, FusedBuf B, unsigned long long* __restrict__ gctr) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t NONE = 0xFFFFFFFFu;
+    const int depth_inner = cam.max_depth - 1;
+    // the lane's path
+    bool active = false, first = true;
+    uint32_t unit = 0;
+    Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
+    Rng g; g.key = 0; g.k = 0; g.bounce = 0;
+    V3 L0 = mk(0, 0, 0), att0 = mk(0, 0, 0), L = mk(0, 0, 0), beta = mk(1, 1, 1);
+    int b_inner = 0;
+    // the wave's chunk of work units
+    uint32_t chunk_next = 0, chunk_end = 0, shard = wave_id % ST_SHARDS, shards_tried = 0;
+    bool units_left = true;
+    uint32_t cn[4] = {0, 0, 0, 0}, c_samp = 0, c_seg = 0, c_hit = 0;
+    unsigned long long c_draws = 0;
+    const unsigned long long n_chunks = ((unsigned long long)B.n_units + ST_FUSED_CHUNK - 1) / ST_FUSED_CHUNK;
+    for (;;) {
+        // ---- regeneration: idle lanes take the wave's next units
+        const unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && units_left) {
+            uint32_t want = (uint32_t)__popcll(idle);
+            while (chunk_next >= chunk_end && units_left) {
+                uint32_t nb = 0;
+                if (lane == 0) nb = atomicAdd(&B.uctl[32 * shard], 1u);
+                nb = __builtin_amdgcn_readfirstlane(nb);
+                const unsigned long long c = (unsigned long long)nb * ST_SHARDS + shard;   // chunk index
+                if (c < n_chunks) {
+                    chunk_next = (uint32_t)(c * ST_FUSED_CHUNK);
+                    const unsigned long long e = c * ST_FUSED_CHUNK + ST_FUSED_CHUNK;
+                    chunk_end = e < (unsigned long long)B.n_units ? (uint32_t)e : B.n_units;
+                } else {
+                    shard = (shard + 1) % ST_SHARDS;
+                    if (++shards_tried >= ST_SHARDS) units_left = false;
+                }
+            }
+            if (!units_left) want = 0;
+            if (want > chunk_end - chunk_next) want = chunk_end - chunk_next;
+            const uint32_t base = chunk_next;
+            chunk_next += want;
+            if (!active) {
+                const uint32_t my = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (my < want) {
+                    unit = base + my;
+                    const uint32_t pix_i = unit / B.spp, sample = unit - pix_i * B.spp;
+                    const uint32_t pk = B.pixels[pix_i];
+                    const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
+                    g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)sample); g.k = 0; g.bounce = 0;
+                    ray = camera_ray(cam, px, py, g);
+                    first = true; active = true;
+                    if (COUNT) c_samp++;
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) { if (!units_left) break; else continue; }
+        // ---- one segment for every active lane: closest hit over all leaf objects, then the shading of the winner
+        double t_hit; uint32_t kind, idx;
+        brute_hit<LEVEL, COUNT>(sc, ray, g, t_hit, kind, idx, cn);
+        if (active) {
+            g.bounce++;
+            if (COUNT) { c_seg++; if (kind != NONE) c_hit++; }
+            bool ended = false;
+            V3 rad = mk(0, 0, 0);
+            if (kind == NONE) {
+                const V3 bg = background(sc, env, ray.d);
+                rad = first ? bg : L0 + att0 * (L + beta * bg);   // camera.hpp:520 / 941, 1000
+                ended = true;
+            } else {
+                Rec rec;
+                object_rec(sc, kind, idx, ray, t_hit, rec);
+                const V3 em = emitted(sc, rec);
+                V3 att; Ray nr;
+                const bool sc_ok = scatter(sc, ray, rec, att, nr, g);
+                if (first) {   // ray_color_from_hit, camera.hpp:989-1004
+                    L0 = em;
+                    if (!sc_ok || depth_inner <= 0) { rad = L0; ended = true; }
+                    else { att0 = att; L = mk(0, 0, 0); beta = mk(1, 1, 1); b_inner = 0; first = false; ray = nr; }
+                } else {       // body of ray_color's loop, camera.hpp:944-983
+                    L = L + beta * em;
+                    bool stop = !sc_ok;
+                    if (!stop) {
+                        beta = beta * att;
+                        if (b_inner > 10) {
+                            if (len(beta) < 0.0001) stop = true;
+                            else {
+                                double p = fmax(fmax(beta.x, beta.y), beta.z);
+                                p = clampd(p, 0.05, 0.95);
+                                if (g.next() > p) stop = true; else beta = beta * (1 / p);
+                            }
+                        }
+                    }
+                    if (!stop) { b_inner++; if (b_inner >= depth_inner) stop = true; }
+                    if (stop) { rad = L0 + att0 * L; ended = true; } else ray = nr;
+                }
+            }
+            if (ended) {
+                double* pp = B.samples + (size_t)unit * 3;
+                pp[0] = rad.x; pp[1] = rad.y; pp[2] = rad.z;
+                if (COUNT) c_draws += g.k;
+                active = false;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&gctr[0], (unsigned long long)c_samp); atomicAdd(&gctr[1], (unsigned long long)c_seg);
+        atomicAdd(&gctr[3], (unsigned long long)cn[0]); atomicAdd(&gctr[4], (unsigned long long)cn[1]); atomicAdd(&gctr[5], (unsigned long long)cn[2]); atomicAdd(&gctr[6], (unsigned long long)cn[3]);
+        atomicAdd(&gctr[7], (unsigned long long)c_hit); atomicAdd(&gctr[8], c_draws);
+    }
+}
+
 // THE DRAIN.  Once the last work unit has been handed out a frame lives on its longest paths: cfg5 (depth 50) spends 36 of its
 // 118 rounds on a pool that is almost empty, and a round costs 0.8 ms however few paths it carries (every EXTEND wave still
 // walks its share of the slot pool to find them).  So when no unit is left and fewer than 1/16 of the slots are active, the
@@ -1033,6 +1197,35 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
     else if (out) hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, A, cam, out);
     if (timer) timer->end(stream, 3);
     if (rounds_out) *rounds_out = cancelled ? -rounds : rounds;
+    return hipGetLastError();
+}
+
+// the fused small-scene render: one persistent launch over all units, then the pipeline's reduce.  `level`: 1 = no wrapped objects
+// and only plain media, 2 = everything but placements
+int fused_blocks() {
+    int dev = 0, cus = 256, per_cu = 2;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_render<2, false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    return cus * per_cu;
+}
+hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
+                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer) {
+    const uint32_t n_units = n_pix * spp;
+    const size_t W = stream_ctl_words();
+    hipError_t e;
+    if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+    FusedBuf B; B.pixels = d_pixels; B.samples = d_samples; B.uctl = d_ctl + (size_t)ST_MAX_POOLS * W; B.spp = spp; B.n_units = n_units;
+    const unsigned long long n_chunks = ((unsigned long long)n_units + ST_FUSED_CHUNK - 1) / ST_FUSED_CHUNK;
+    unsigned long long want_blocks = (n_chunks + 3) / 4;   // no more waves than chunks
+    const dim3 grid((unsigned)(want_blocks < (unsigned long long)blocks ? (want_blocks ? want_blocks : 1) : blocks)), block(256);
+    if (timer) timer->begin(stream, 1);
+    if (level <= 1) { if (count) hipLaunchKernelGGL((fused_render<1, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); else hipLaunchKernelGGL((fused_render<1, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); }
+    else { if (count) hipLaunchKernelGGL((fused_render<2, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); else hipLaunchKernelGGL((fused_render<2, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); }
+    if (timer) timer->end(stream, 1);
+    StreamBuf R = make_buf(nullptr, 0, spp, n_units, n_pix, d_pixels, d_samples, d_ctl, d_ctl, 0, 0);
+    if (timer) timer->begin(stream, 3);
+    if (out) hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, R, cam, out);
+    if (timer) timer->end(stream, 3);
     return hipGetLastError();
 }
 
