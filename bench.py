@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 RANDOM_RECORD_PEAK_G = 60.0   # G dependent random records/s beyond L2, measured on MI355X by scripts/dev/randread.hip (profiles/README.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_FLOPS = 256 * 4 * 16 * 2 * 2.4e9   # FP64 vector: 256 CUs x 4 SIMDs x 16 lanes x 2 flops (FMA) x 2.4 GHz = 78.6 TFLOP/s
 
 
 def kernel_src_sha():
@@ -72,8 +73,8 @@ def host_threads():
 
 def cpu_baseline(workload):
     """The reference's CPU arithmetic (oracle/_ref: genuine headers compiled in the build container) on a bounded sample of the
-    same workload on ALL host cores this process may use, and the CPU restatement (oracle/libzr_oracle.so, "port") on the same
-    pixels and samples beside it."""
+    same workload at its best thread count (median of 3) and on all host cores this process may use, and the CPU restatement
+    (oracle/libzr_oracle.so, "port") on the same pixels and samples beside it."""
     from oracle import zr_oracle_py as zo
     from raytracer_project_amd import capi
     xs, spp = CPU_SAMPLE[workload]
@@ -94,19 +95,25 @@ def cpu_baseline(workload):
     if not zo.ref_available():
         port["host_cores"] = os.cpu_count()
         return port
-    r = zo.ref_run("time", scene, xs, 1, spp, threads)
+    # The reference at its BEST thread count is the headline: its hit_record copies a shared_ptr<material> per candidate, whose
+    # refcounts ping-pong between cores, so on a many-core host it is faster at 16 threads than on all of them (measured: 4.1 against
+    # 2.2 Msamples/s on the 256-thread box).  Median of 3 runs at 16 threads; one run on all cores is printed beside it.
+    best_threads = min(16, threads)
+    runs = sorted((zo.ref_run("time", scene, xs, 1, spp, best_threads) for _ in range(3)), key=lambda q: q["mseg_per_s"])
+    r = runs[1]
     same = r["segments"] == ctr.segments and abs(float(frame.sum()) - r["checksum"]) <= 1e-9 * max(1.0, abs(r["checksum"]))
-    few = None
-    if threads > 16:   # the reference's hit_record copies a shared_ptr<material> per candidate: on many cores its refcounts ping-pong
-        r16 = zo.ref_run("time", scene, xs, 1, spp, 16)
-        few = {"value": round(r16["mseg_per_s"], 4), "cores": 16, "render_s": round(r16["render_s"], 1)}
-    return {"value": round(r["mseg_per_s"], 4), "unit": "Msamples/s", "cores": threads, "kind": "reference", "host_cores": os.cpu_count(),
+    every = None
+    if threads > best_threads:
+        ra = zo.ref_run("time", scene, xs, 1, spp, threads)
+        every = {"value": round(ra["mseg_per_s"], 4), "cores": threads, "render_s": round(ra["render_s"], 1)}
+    return {"value": round(r["mseg_per_s"], 4), "unit": "Msamples/s", "cores": best_threads, "kind": "reference", "host_cores": os.cpu_count(),
+            "runs": [round(q["mseg_per_s"], 4) for q in runs],
             "sample": f"every {xs}th column of every row of the frame at {spp} spp ({r['primary']} primary samples, "
-                      f"{r['segments']} segments, {r['render_s']:.1f} s; the reference's median-split BVH build, {r['bvh_build_s']:.1f} s, is not counted); "
+                      f"{r['segments']} segments, {r['render_s']:.1f} s, median of 3; the reference's median-split BVH build, {r['bvh_build_s']:.1f} s, is not counted); "
                       "genuine reference hit / scatter / BVH / camera functions with the per-(pixel, sample) counter RNG in place of its "
-                      "shared mt19937 (no cache-line ping-pong between threads: this number flatters the reference), rows dealt to "
-                      f"{threads} threads dynamically",
-            "reference_at_16_threads": few, "port": port, "port_matches_reference": bool(same)}
+                      "shared mt19937 (no cache-line ping-pong between threads on the engine: this number flatters the reference), rows dealt to "
+                      f"{best_threads} threads dynamically — the reference's best thread count on this host",
+            "reference_on_all_cores": every, "port": port, "port_matches_reference": bool(same)}
 
 
 def self_launch(n):
@@ -189,7 +196,7 @@ def main():
     acc = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
     region = multi.tile_region(capi, rank, world)
     if os.environ.get("ZR_BENCH_SHARD_OF"):  # development aid: time one rank's share of an N-way sharded frame on one GPU
-        region = multi.tile_region(capi, 0, int(os.environ["ZR_BENCH_SHARD_OF"]))
+        region = multi.tile_region(capi, int(os.environ.get("ZR_BENCH_SHARD_RANK", "0")), int(os.environ["ZR_BENCH_SHARD_OF"]))
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step(count=False):
@@ -209,7 +216,7 @@ def main():
     seg_local = ctr.segments
     # the dominant kernel of the streaming pipeline is EXTEND (BVH walk): it owns the box / primitive bytes; the 76 B of
     # shading data per hit belong to the SHADE kernel and are left out of the EXTEND roofline
-    bytes_local = ctr.algorithmic_bytes() - (76 * ctr.hits if int(os.environ.get("ZR_KERNEL", "2")) == 2 else 0)
+    bytes_local = ctr.algorithmic_bytes() - (76 * ctr.hits if int(getattr(ctr, "path", 2)) in (2, 3) else 0)
     segments, alg_bytes, primary = multi.all_reduce_values([seg_local, bytes_local, ctr.primary_samples], world, dev)
     checksum = float(acc.sum().item()) if rank == 0 else 0.0
 
@@ -225,7 +232,8 @@ def main():
     dt = multi.all_reduce_values([dt], world, dev, op="max")[0]
     launches = ctx.kernel_times_ms(1 << 20)  # dominant kernel's launches (HIP events on the launch stream), timed steps only
     variant = int(os.environ.get("ZR_KERNEL", "2"))
-    kernel_name = {0: "render_pixels", 2: "stream_extend"}.get(variant, "render_pixels")
+    path = int(getattr(ctr, "path", 2 if variant == 2 else 0))   # which kernels rendered the frame (zr_counters::path)
+    kernel_name = {0: "render_pixels", 2: "stream_extend", 3: "fused_render"}.get(path, "render_pixels")
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -237,11 +245,11 @@ def main():
         achieved = (bytes_local / launches_per_step) / (k_ms * 1e-3) * 1e-9 if k_ms > 0 else 0.0
         # the same traversal priced on THIS layout (what a no-reuse walk of the stored data would move): 64 B per 4-wide node
         # fetched (the root's four boxes travel in the kernel arguments), 72 B / 32 B / 48 B per triangle / sphere / cube tested
-        layout_bytes = (64 * ctr.node_lanes + 72 * ctr.triangles_tested + 32 * ctr.spheres_tested + 48 * ctr.cubes_tested) if variant == 2 else None
+        layout_bytes = (64 * ctr.node_lanes + 72 * ctr.triangles_tested + 32 * ctr.spheres_tested + 48 * ctr.cubes_tested) if path == 2 else None
         achieved_layout = (layout_bytes / launches_per_step) / (k_ms * 1e-3) * 1e-9 if (layout_bytes and k_ms > 0) else None
-        # memory-side bytes per launch of the dominant kernel from the newest committed counter pass of THIS kernel source
-        # (separate --pmc runs: scripts/profile_round.sh); a pass taken on other sources is stale and reported as null
-        traffic, traffic_file = None, None
+        # counter passes of the dominant kernel from the newest committed file of THIS kernel source (separate --pmc runs:
+        # scripts/profile_round.sh); a pass taken on other sources is stale and reported as null
+        traffic, traffic_file, kj = None, None, {}
         if world == 1 and args.spp == 0:
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_traffic.json")), key=_round_key, reverse=True):
                 try:
@@ -253,14 +261,35 @@ def main():
                     traffic_file = os.path.relpath(f, ROOT)
                     break
                 except Exception:
+                    kj = {}
                     continue
         node_util = ctr.node_lanes / max(1, ctr.node_execs) / 64.0
         leaf_util = ctr.leaf_lanes / max(1, ctr.leaf_execs) / 64.0
         # every lane-step of the walk fetches ONE randomly placed record (a 64-B node, a 72-B triangle, a 32-B sphere ...): the
         # rate at which the chip serves dependent random records is what the kernel runs against (scripts/dev/randread.hip, same
         # occupancy: ~60 G records/s from arrays beyond the L2s whatever the record size up to 128 B, ~206 G/s L2-resident)
-        records = (ctr.node_lanes + ctr.triangles_tested + ctr.spheres_tested + ctr.cubes_tested + ctr.media_tested) if variant == 2 else None
+        records = (ctr.node_lanes + ctr.triangles_tested + ctr.spheres_tested + ctr.cubes_tested + ctr.media_tested) if path == 2 else None
         rec_rate = (records / launches_per_step) / (k_ms * 1e-3) * 1e-9 if (records and k_ms > 0) else None
+        # WHAT BOUNDS the dominant kernel, per workload.  From the counter file when one of this kernel source exists (L2 hit rate,
+        # FP64 issue), else from the working set: a world whose nodes + primitives fit the 32 MiB of L2 runs out of the caches and is
+        # limited by FP64 vector issue; beyond that the walk is limited by the rate at which dependent random records come back
+        # through L2 and the fabric.  The fused kernel keeps everything in registers / scalar loads: FP64 issue by construction.
+        l2_hit = kj.get("l2_hit_rate")
+        valu_issue = kj.get("valu_issue_frac")
+        fp64_flops = kj.get("fp64_flops_per_launch")
+        fp64_frac = round(fp64_flops / (k_ms * 1e-3) / FP64_PEAK_FLOPS, 4) if (fp64_flops and k_ms > 0) else None
+        if path == 3:
+            bound, why = "fp64-valu", "fused small-scene kernel: path state in registers, objects through scalar loads; HBM sees 24 B per sample"
+        elif stats["device_bytes"] <= 32 * 2**20:
+            bound, why = "fp64-valu", f"nodes + primitives ({stats['device_bytes']} B) fit the 8 x 4 MiB of L2: the walk's records are cache hits, the FP64 primitive tests and the pipeline's own state traffic remain"
+        else:
+            bound, why = "l2-request-rate", (f"nodes + primitives ({stats['device_bytes'] >> 20} MiB) exceed L2: every lane-step fetches one randomly placed record; the kernel moves "
+                                            "them at random_record_rate_G_per_s against ~60 G/s beyond L2 / ~206 G/s L2-resident (scripts/dev/randread.hip)")
+        if path == 2 and valu_issue is not None and valu_issue >= 0.7:
+            # the counters overrule the guess: the walk's vector instructions (FP32 slab tests, the sort of four children, FP64 primitive tests) fill the issue slots
+            bound, why = "valu-issue", (f"SQ_INSTS_VALU x 4 cycles fill {100 * valu_issue:.0f} % of the chip's vector issue slots over the kernel's active cycles (1024 SIMDs): the walk is limited by "
+                                        f"the instructions it executes at {100 * node_util:.0f} % / {100 * leaf_util:.0f} % lane utilisation of its NODE / LEAF phases, not by memory (L2 hit rate {l2_hit})")
+        bound_source = (f"counters: {traffic_file}" if (l2_hit is not None or fp64_frac is not None or valu_issue is not None) else "working set vs L2 (no counter pass of this kernel source committed)")
         out = {
             "metric": "Msamples/sec (rays·bounces)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -272,32 +301,32 @@ def main():
                        "bvh_pairs": stats["bvh_pairs"], "bvh_depth": stats["bvh_depth"], "objects": stats["objects"],
                        "traversal_stack": stats.get("traversal_stack"),
                        "scene_build_s": round(t_scene, 3), "bvh_build_upload_s": round(t_commit, 3), "bvh_build_upload_first_s": round(t_commit_first, 3),
-                       "bvh_builder": stats.get("builder"),
+                       "bvh_builder": stats.get("builder"), "render_path": {0: "pixel-group megakernel", 2: "streaming pipeline", 3: "fused small-scene kernel"}.get(path),
                        "frame_checksum": checksum},
             # `achieved` / `frac`: SURVEY 8(d)'s ALGORITHMIC bytes (a work rate: the no-reuse BVH2-style model) per launch / launch
-            # duration.  It is NOT memory headroom: `frac_layout` prices the same traversal on the stored layout and
-            # `frac_traffic` is what the memory-side counters saw; `bound_note` says what the kernel is limited by.
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # duration against the HBM peak — the figure the contract asks for.  It is NOT memory headroom: `bound` names what the
+            # kernel is limited by, `frac_layout` prices the same traversal on the stored layout, `frac_traffic` is what the
+            # memory-side counters saw.
+            "roofline": {"bound": bound, "bound_why": why, "bound_source": bound_source,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_file,
                          "frac_traffic": round(traffic / (k_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 5) if (traffic and k_ms > 0) else None,
+                         "l2_hit_rate": l2_hit,
+                         "valu_issue_frac": valu_issue, "fp64_valu_frac": fp64_frac, "fp64_peak_tflops": FP64_PEAK_FLOPS * 1e-12,
                          "achieved_layout": round(achieved_layout, 2) if achieved_layout else None,
                          "frac_layout": round(achieved_layout / HBM_PEAK_GBS, 5) if achieved_layout else None,
                          "random_records_per_launch": int(records / launches_per_step) if records else None,
                          "random_record_rate_G_per_s": round(rec_rate, 2) if rec_rate else None,
-                         "random_record_peak_G_per_s": RANDOM_RECORD_PEAK_G,
+                         "random_record_peak_G_per_s": RANDOM_RECORD_PEAK_G if records else None,
                          "frac_random_records": round(rec_rate / RANDOM_RECORD_PEAK_G, 4) if rec_rate else None,
-                         "bound_note": ("not bound by HBM bytes: every lane-step of the walk fetches one randomly placed record (node / triangle / sphere), "
-                                        f"and the kernel moves them at random_record_rate_G_per_s against the ~{RANDOM_RECORD_PEAK_G:.0f} G records/s this chip serves "
-                                        "dependent random records from arrays beyond its L2s at the same occupancy (scripts/dev/randread.hip; ~206 G/s L2-resident; "
-                                        "about half the walk's requests hit L2).  Round-2 experiments (profiles/r2_experiments_ab.txt): more ready lanes per "
-                                        f"iteration (now {100 * node_util:.0f} % NODE / {100 * leaf_util:.0f} % LEAF), merged node+leaf iterations, an LDS copy of the tree top, "
-                                        "prefetch touches and 128-byte-aligned triangles all left the time where it is or raised it; one more request per node visit costs 10 %.  "
-                                        "frac is the algorithmic work rate SURVEY 8(d) defines, frac_traffic the counter bytes over the same time"),
+                         "lane_utilisation": {"node": round(node_util, 3), "leaf": round(leaf_util, 3)} if path == 2 else None,
                          "kernel": kernel_name, "kernel_ms": round(k_ms, 4), "launches_timed": len(launches),
                          "kernel_ms_per_step": round(sum(launches) / max(1, args.steps), 3),
                          "algorithmic_bytes_per_launch": int(bytes_local / launches_per_step),
-                         "model": "32 B/child box tested + 72 B/triangle + 32 B/sphere + 48 B/cube + 76 B/hit (SURVEY §8d)"},
+                         "model": ("32 B per child box tested + 72 B per triangle + 32 B per sphere + 48 B per cube test (SURVEY 8(d) prices a cube at 96 B; this layout stores 6 of "
+                                   "its 12 doubles — a placed cube's record is 96 B — so the figure is conservative); the 76 B per hit of shading data belong to SHADE "
+                                   "and are NOT in this kernel's figure")},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

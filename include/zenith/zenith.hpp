@@ -22,6 +22,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1038,16 +1040,53 @@ inline zr_env to_zr_env(const EnvironmentSettings& e, scene_builder& b) {
     z.sun_intensity = e.sun_intensity; z.sun_size = e.sun_size;
     return z;
 }
-// one device context per host thread AND device ordinal, created on first use
-inline zr_ctx* thread_context(int device = 0) {
-    struct holder { std::unordered_map<int, zr_ctx*> c; ~holder() { for (auto& kv : c) if (kv.second) zr_destroy(kv.second); } };
-    static thread_local holder h;
-    auto it = h.c.find(device);
-    if (it != h.c.end()) return it->second;
-    zr_ctx* c = zr_create(device);
-    if (c) h.c[device] = c;
-    return c;
-}
+// Device contexts are kept in ONE process-wide pool, per device ordinal, and LEASED for the duration of a call: the reference
+// starts a fresh thread for every render (main.cpp:1520-1531), and a context per thread would create — and free — the
+// pipeline's buffers (tens of GB for a 1080p frame at 512 spp) on every restart.  A lease is exclusive (a zr_ctx serves one
+// caller at a time); threads that render one after the other reuse the same context, threads that render at the same time get
+// one each.  The pool lives as long as the process.
+struct context_pool {
+    struct entry { zr_ctx* c; int device; bool busy; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<entry> all;
+    ~context_pool() { for (entry& e : all) if (e.c) zr_destroy(e.c); }
+    zr_ctx* acquire(int device) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (entry& e : all) if (e.device == device && !e.busy) { e.busy = true; return e.c; }
+        }
+        zr_ctx* c = zr_create(device);   // (outside the lock: creating a context takes milliseconds)
+        if (!c) return nullptr;
+        std::lock_guard<std::mutex> lk(m);
+        all.push_back(entry{c, device, true});
+        return c;
+    }
+    void acquire(zr_ctx* c) {   // a particular context (the one a cached scene was committed on): wait until it is free
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { for (entry& e : all) if (e.c == c) return !e.busy; return true; });
+        for (entry& e : all) if (e.c == c) e.busy = true;
+    }
+    void release(zr_ctx* c) {
+        { std::lock_guard<std::mutex> lk(m); for (entry& e : all) if (e.c == c) e.busy = false; }
+        cv.notify_all();
+    }
+    size_t created() { std::lock_guard<std::mutex> lk(m); return all.size(); }
+};
+inline context_pool& contexts() { static context_pool p; return p; }
+// contexts created by this process so far (tests: three renders from three successive threads create one)
+inline size_t contexts_created() { return contexts().created(); }
+struct context_lease {
+    zr_ctx* ctx;
+    explicit context_lease(int device) : ctx(contexts().acquire(device)) {}
+    explicit context_lease(zr_ctx* c) : ctx(c) { if (c) contexts().acquire(c); }
+    context_lease(const context_lease&) = delete;
+    context_lease& operator=(const context_lease&) = delete;
+    ~context_lease() { if (ctx) contexts().release(ctx); }
+    operator zr_ctx*() const { return ctx; }
+};
+// the device hit() / scatter() calls of scene objects use: the one of the camera that rendered last (camera::device), 0 before that
+inline std::atomic<int>& object_device() { static std::atomic<int> d{0}; return d; }
 
 // ---- callable hit() / scatter(): one ray through the device ---------------------------------------------------------
 // The object is flattened once and committed as a scene of its own (cached in the object, per context; set_material drops
@@ -1057,18 +1096,19 @@ inline zr_ctx* thread_context(int device = 0) {
 // i.e. the call consumes random_double() exactly as the reference's scatter would (common.hpp:29-34, material.hpp).
 // A constant_medium draws its distance from the off-stream medium key of the current stream position (zr_rng.h).
 struct device_object {
-    zr_ctx* ctx = nullptr; zr_scene* sc = nullptr;
+    zr_ctx* ctx = nullptr; zr_scene* sc = nullptr; int device = 0;
     flat_scene fs;
     std::unordered_map<uint32_t, shared_ptr<material>> mats;
-    ~device_object() { if (sc) zr_scene_destroy(sc); }
+    ~device_object() { if (sc) zr_scene_destroy(sc); }   // (frees the scene's device arrays; touches no context state: no lease)
 };
 template <class Flatten>
 inline shared_ptr<device_object> device_commit(shared_ptr<device_object>& cache, const char* what, Flatten&& flatten) {
-    zr_ctx* ctx = thread_context(0);
+    if (cache && cache->device == object_device().load()) return cache;   // committed before, on a context of this device (which the pool keeps alive)
+    context_lease lease(object_device().load());
+    zr_ctx* ctx = lease;
     if (!ctx) throw std::runtime_error(std::string(what) + ": no device context: " + zr_last_error());
-    if (cache && cache->ctx == ctx) return cache;
     auto d = make_shared<device_object>();
-    d->ctx = ctx;
+    d->ctx = ctx; d->device = object_device().load();
     scene_builder b(d->fs);
     flatten(b);
     b.finish();
@@ -1089,6 +1129,7 @@ inline bool device_hit(const hittable& self, const ray& r, const interval& ray_t
     const double rays6[6] = {r.origin().x(), r.origin().y(), r.origin().z(), r.direction().x(), r.direction().y(), r.direction().z()};
     host_rng& g = rng_state();
     zr_hit h{};
+    context_lease lease(d->ctx);   // the object's scene lives on that context: exclusive for the call
     // stream key of this call = (host key, host draw position, 0): a medium's off-stream draw changes as the host stream advances
     if (zr_trace(d->ctx, d->sc, rays6, 1, ray_t.min, ray_t.max, g.key, g.k, 0, &h) != ZR_OK) throw std::runtime_error(std::string("hittable::hit: ") + zr_last_error());
     if (!d->fs.media.empty()) g.k++;   // constant_medium::hit consumes a draw (constant_medium.hpp:64)
@@ -1111,6 +1152,7 @@ inline bool device_scatter(const material& self, const ray& r_in, const hit_reco
     h.t = rec.t; h.u = rec.u; h.v = rec.v; h.mat = id; h.front_face = rec.front_face ? 1u : 0u;
     host_rng& g = rng_state();
     zr_scatter_out o{};
+    context_lease lease(d->ctx);
     if (zr_kat_scatter(d->ctx, d->sc, rays6, &h, &g.key, &g.k, 1, &o) != ZR_OK) throw std::runtime_error(std::string("material::scatter: ") + zr_last_error());
     g.k += o.draws;
     if (!o.scattered) return false;
@@ -1159,7 +1201,8 @@ public:
     bool process_framebuffer(const std::vector<color>& buffer, const post_processor& pp, std::vector<unsigned char>& rgb8,
                              bool is_data_pass = false, bool apply_gamma = true) const {
         rgb8.assign((size_t)image_width * image_height * 3, 0);
-        zr_ctx* ctx = zenith::thread_context(device);
+        zenith::context_lease lease(device);
+        zr_ctx* ctx = lease;
         if (!ctx || buffer.size() != (size_t)image_width * image_height) { std::cerr << "[zenith] process_framebuffer: " << (ctx ? "buffer size mismatch" : zr_last_error()) << "\n"; return false; }
         zr_post_params p = pp.to_zr();
         int rc = zr_post_process(ctx, &p, reinterpret_cast<const double*>(buffer.data()), image_width, image_height, is_data_pass, apply_gamma, rgb8.data());
@@ -1169,7 +1212,8 @@ public:
     // post_processor::analyze_framebuffer (color_processing.hpp:150-183) on the device
     image_statistics analyze(const std::vector<color>& buffer) const {
         image_statistics st;
-        zr_ctx* ctx = zenith::thread_context(device);
+        zenith::context_lease lease(device);
+        zr_ctx* ctx = lease;
         zr_image_stats z{};
         if (ctx && !buffer.empty() && zr_analyze_frame(ctx, reinterpret_cast<const double*>(buffer.data()), buffer.size(), &z) == ZR_OK) {
             st.average_luminance = z.average_luminance; st.max_luminance = z.max_luminance;
@@ -1192,11 +1236,15 @@ public:
         b.finish();
         zr_env zenv = zenith::to_zr_env(env, b);
         for (const auto& w : fs.warnings) std::cerr << "[zenith] " << w << "\n";
-        zr_ctx* ctx = zenith::thread_context(device);
+        zenith::object_device() = device;
+        int rc;
+        {
+        zenith::context_lease lease(device);   // one context of the process-wide pool, exclusively, for this frame
+        zr_ctx* ctx = lease;
         if (!ctx) { std::cerr << "[zenith] render failed: " << zr_last_error() << "\n"; return; }
         zr_scene* sc = zr_scene_create(ctx);
         zr_scene_desc d = fs.desc();
-        int rc = sc ? zr_scene_set_all_borrowed(sc, &d) : ZR_E_DEVICE;
+        rc = sc ? zr_scene_set_all_borrowed(sc, &d) : ZR_E_DEVICE;
         if (rc == ZR_OK) rc = zr_scene_commit(sc);
         if (rc == ZR_OK) {
             zr_camera zc{};
@@ -1227,11 +1275,12 @@ public:
             }
         }
         if (rc != ZR_OK && rc != ZR_E_CANCELLED) std::cerr << "[zenith] render failed: " << zr_last_error() << "\n";
+        if (sc) zr_scene_destroy(sc);
+        }   // (the lease ends here: analyze() below takes its own)
         if (rc == ZR_OK && post.use_auto_exposure) {   // camera.hpp:258-266
             image_statistics stats = analyze(render_accumulator);
             post.last_stats = stats;
             post.exposure = static_cast<float>(post.apply_auto_exposure(stats));
         }
-        if (sc) zr_scene_destroy(sc);
     }
 };

@@ -189,6 +189,8 @@ typedef struct zr_counters {
     uint64_t rounds;         /* kernel variant 2: EXTEND/SHADE rounds of the last render */
     double extend_ms, shade_ms; /* kernel variant 2: device time of the EXTEND / SHADE launches of the last render */
     double kernel_ms;        /* device time of the render kernels of the last call (hipEvents) */
+    uint64_t path;           /* which kernels rendered the last frame: 0 pixel-group megakernel (fallback), 2 streaming pipeline
+                                (EXTEND / SHADE rounds), 3 fused small-scene kernel (worlds of at most ZR_FUSED_MAX objects) — ABI 3 */
 } zr_counters;
 
 /* hit record returned by zr_trace (debug / known-answer entry): hit_record, hittable.hpp:9-26 */

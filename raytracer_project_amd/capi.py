@@ -99,7 +99,7 @@ class Counters(C.Structure):
                 ("media_tested", C.c_uint64), ("hits", C.c_uint64), ("rng_draws", C.c_uint64),
                 ("node_execs", C.c_uint64), ("node_lanes", C.c_uint64), ("leaf_execs", C.c_uint64), ("leaf_lanes", C.c_uint64),
                 ("shade_execs", C.c_uint64), ("shade_lanes", C.c_uint64), ("rounds", C.c_uint64),
-                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("kernel_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("kernel_ms", C.c_double), ("path", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -275,6 +275,19 @@ class DemoScene:
         if rc != 0:
             raise ZrError(f"drop-in render failed: {load().zr_last_error().decode()}")
         return out, ctr
+
+    def render_dropin_threads(self, n, width=0, height=0, spp=0, device=0):
+        """n drop-in renders, each on a fresh host thread, one after the other (the reference's render-restart pattern,
+        main.cpp:1520-1531): (last frame, device contexts the process has created so far)"""
+        w = width or self.camera.image_width
+        h = height or self.camera.image_height
+        out = np.zeros((h, w, 3), dtype=np.float64)
+        lib = load_scenes()
+        lib.zrs_render_dropin_threads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rc = lib.zrs_render_dropin_threads(self._h, width, height, spp, device, n, out.ctypes.data)
+        if rc < 0:
+            raise ZrError(f"drop-in render failed: {load().zr_last_error().decode()}")
+        return out, rc
 
     def dropin_virtuals(self, rays8, seed, pixel=0x7ACE):
         """bvh_node(world).hit + rec.mat->emitted / scatter through the drop-in classes (one device launch per call):

@@ -31,11 +31,13 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <vector>
 
 #include "zr_build.h"
+#include "zr_bvh.h"
 
 namespace zr {
 namespace {
@@ -345,6 +347,26 @@ __global__ __launch_bounds__(256) void k_ploc_write(const Cl* __restrict__ cin, 
         c.node = id;
     }
     cout[pos] = c;
+}
+
+// The TOP of the tree: PLOC stops at a few thousand clusters and the host's binned-SAH builder (zr_bvh.cpp) arranges them — a
+// bottom-up merger is weakest where a top-down split is strongest, in the few levels every ray crosses.  The host sends only the
+// topology (children of every new node, ids ascending by height so that a level is an id range = a batch); boxes, counts and the
+// leaf decision come from the children here, exactly as at a PLOC merge.
+__global__ __launch_bounds__(256) void k_top_nodes(const uint2* __restrict__ kids, uint32_t id_lo, uint32_t id_hi, uint32_t kid_base, Params prm, BNode* __restrict__ bn,
+                                                   uint32_t* __restrict__ parent, uint32_t* __restrict__ ncount, uint32_t* __restrict__ nmeta, float* __restrict__ ncost) {
+    const uint32_t id = id_lo + blockIdx.x * 256 + threadIdx.x;
+    if (id >= id_hi) return;
+    const uint2 k = kids[id - kid_base];
+    const BNode a = bn[k.x], c = bn[k.y];
+    BNode b;
+    for (int q = 0; q < 3; q++) { b.lo[q] = fminf(a.lo[q], c.lo[q]); b.hi[q] = fmaxf(a.hi[q], c.hi[q]); }
+    b.left = k.x; b.right = k.y;
+    bn[id] = b;
+    parent[k.x] = id; parent[k.y] = id;
+    uint32_t count, meta; float cost;
+    merge_meta(prm, nmeta[k.x], nmeta[k.y], ncount[k.x], ncount[k.y], ncost[k.x], ncost[k.y], half_area(b.lo, b.hi), count, meta, cost);
+    ncount[id] = count; nmeta[id] = meta; ncost[id] = cost;
 }
 
 // ---- 4. order -----------------------------------------------------------------------------------------------------------
@@ -861,7 +883,8 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     if ((e = hipMemcpyAsync(h_state, state + 8, 8 * 4, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;
     if (h_state[6] != 0) { err_ = "an object's box is not finite or beyond 1e18: host builder"; return hipErrorInvalidValue; }
-    while (n_cur > 1) {
+    const uint32_t top = (bp.top_clusters > 1 && (uint64_t)n >= 8ull * (uint64_t)bp.top_clusters) ? (uint32_t)bp.top_clusters : 1u;
+    while (n_cur > top) {
         const uint32_t nb = (n_cur + 255) / 256;
         hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(256), 0, st_, cin, n_cur, prm.radius, nn, act, blk_keep, blk_new);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st_, blk_keep, blk_new, nb, keep_off, new_off, state);
@@ -874,6 +897,53 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
         batch_start.push_back(next_node);
         Cl* sw = cin; cin = cout; cout = sw;
         t.ploc_iterations++;
+    }
+    if (n_cur > 1) {   // the top of the tree over the remaining clusters, by the host's SAH builder
+        std::vector<Cl> hc(n_cur);
+        if ((e = hipMemcpyAsync(hc.data(), cin, (size_t)n_cur * sizeof(Cl), hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;
+        std::vector<BuildBox> tb(n_cur);
+        std::vector<uint32_t> tk(n_cur, 0u);
+        for (uint32_t k = 0; k < n_cur; k++) for (int a = 0; a < 3; a++) { tb[k].lo[a] = hc[k].lo[a]; tb[k].hi[a] = hc[k].hi[a]; }
+        BuildResult tr;
+        const double ck1[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        build_bvh(tb, tk, 1, 26, 1.0, ck1, tr);   // one cluster per leaf; the depth budget leaves the clusters' own subtrees theirs
+        // heights (a leaf = a cluster = height 0), then the inner nodes in ascending height: new id = next_node + position
+        struct TopNode { uint32_t id; int height; };
+        std::vector<TopNode> inner;
+        std::vector<int> height(tr.nodes.size(), -1);
+        {
+            std::vector<std::pair<uint32_t, bool>> stk;   // post-order walk without recursion
+            stk.emplace_back(0u, false);
+            while (!stk.empty()) {
+                auto [id, done] = stk.back(); stk.pop_back();
+                const BuildNode& nd = tr.nodes[id];
+                if (nd.count) { height[id] = 0; continue; }
+                if (!done) { stk.emplace_back(id, true); stk.emplace_back((uint32_t)nd.left, false); stk.emplace_back((uint32_t)nd.right, false); }
+                else { height[id] = 1 + std::max(height[nd.left], height[nd.right]); inner.push_back({id, height[id]}); }
+            }
+        }
+        std::stable_sort(inner.begin(), inner.end(), [](const TopNode& a, const TopNode& b) { return a.height < b.height; });
+        std::vector<uint32_t> new_id(tr.nodes.size(), NONE);
+        for (size_t k = 0; k < inner.size(); k++) new_id[inner[k].id] = next_node + (uint32_t)k;
+        auto node_of = [&](int32_t id) { const BuildNode& nd = tr.nodes[id]; return nd.count ? hc[tr.order[nd.first]].node : new_id[id]; };
+        std::vector<uint2> kids(inner.size());
+        for (size_t k = 0; k < inner.size(); k++) { const BuildNode& nd = tr.nodes[inner[k].id]; kids[k].x = node_of(nd.left); kids[k].y = node_of(nd.right); }
+        if (inner.size() + 1 != (size_t)n_cur) { err_ = "top tree: node count mismatch (internal error)"; return hipErrorUnknown; }
+        uint2* d_kids = (uint2*)nn;   // (free now: n_cur - 1 pairs of ids fit the n words of the neighbour array)
+        if ((e = hipMemcpyAsync(d_kids, kids.data(), kids.size() * sizeof(uint2), hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
+        const uint32_t kid_base = next_node;
+        for (size_t k = 0; k < inner.size();) {   // one launch per height level: its children are complete
+            size_t k1 = k;
+            while (k1 < inner.size() && inner[k1].height == inner[k].height) k1++;
+            const uint32_t lo = next_node + (uint32_t)k, hi = next_node + (uint32_t)k1;
+            hipLaunchKernelGGL(k_top_nodes, grid_for(hi - lo), dim3(256), 0, st_, d_kids, lo, hi, kid_base, prm, bn, parent, ncount, nmeta, ncost);
+            batch_start.push_back(hi);
+            k = k1;
+        }
+        if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;   // (kids[] is read by the copy until here)
+        next_node += (uint32_t)inner.size();
+        n_cur = 1;
     }
     lap(2);
     const uint32_t n_nodes = next_node;                  // = 2n - 1

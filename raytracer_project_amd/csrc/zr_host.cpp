@@ -123,6 +123,7 @@ struct zr_ctx {
     unsigned int* h_active = nullptr;     // pinned
     std::vector<int32_t> pix_key;         // plan the cached pixel list was built for
     uint64_t last_rounds = 0;
+    int last_path = 0;                    // zr_counters::path of the last render
     double last_extend_ms = 0, last_shade_ms = 0;
     // device timing of render-kernel launches: HIP events recorded on the stream the kernel is launched on
     struct Pending { hipEvent_t a, b; uint64_t render_id; int kind; };
@@ -1196,6 +1197,7 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     for (int k = 0; k < 8; k++) bp.leaf_cap[k] = leaf_cap[k];
     bp.open_ratio = (float)env_double("ZR_BVH_OPEN_RATIO", 1.25);
     bp.radius = (int)env_double("ZR_BVH_PLOC_RADIUS", 16);
+    bp.top_clusters = (int)env_double("ZR_BVH_TOP", 16384);
     zr::BuildPrimOut out;
     out.spheres = s->d_spheres.p; out.sphere_mat = s->d_sphere_mat.p; out.tri_v = s->d_tri_v.p; out.tri_s = s->d_tri_s.p;
     out.cubes = s->d_cubes.p; out.cube_mat = s->d_cube_mat.p; out.pcubes = s->d_pcubes.p; out.pcube_mat = s->d_pcube_mat.p;
@@ -1541,11 +1543,13 @@ int zr_scene_commit(zr_scene* s) {
     if (rc) return rc;
     phase("world list + validate");
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
-    {   // which builder.  ZR_BVH_BUILD=device | host forces one; otherwise worlds of at least ZR_BVH_DEVICE_MIN entries are built
-        // on the device (a small world is built faster by the host than a few dozen kernel launches take)
+    {   // which builder.  ZR_BVH_BUILD=device | host forces one; otherwise worlds of at least ZR_BVH_DEVICE_MIN entries (131072: from
+        // there on the device build's top is arranged by SAH, zr_build.h) are built on the device: cfg3's 1M triangles commit in
+        // 19 ms instead of 95 and EXTEND walks the tree 2 % slower (cfg3w: 3.5 %) — profiles/r3_builders.txt; a small world is
+        // built faster by the host than a few dozen kernel launches take
         const char* bm = std::getenv("ZR_BVH_BUILD");
         const bool force_dev = bm && std::strcmp(bm, "device") == 0, force_host = bm && std::strcmp(bm, "host") == 0;
-        const bool use_dev = !force_host && !objs.empty() && objs.size() < (1u << 30) && (force_dev || (double)objs.size() >= env_double("ZR_BVH_DEVICE_MIN", 1e18));
+        const bool use_dev = !force_host && !objs.empty() && objs.size() < (1u << 30) && (force_dev || (double)objs.size() >= env_double("ZR_BVH_DEVICE_MIN", 131072));
         if (use_dev) {
             CommitSummary cs;
             rc = commit_device(s, objs, commit_stats, cs);
@@ -1872,10 +1876,11 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
         hipError_t fe = zr::fused_render_frame(s->ds, dc, de, seed, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p, c->fused_blocks, d_out, c->d_ctr.p, count != 0,
                                                s->leaf_level <= 1 ? 1 : 2, stream, &ftimer);
         if (fe != hipSuccess) return fail(ZR_E_DEVICE, "fused small-scene kernel failed: %s", hipGetErrorString(fe));
-        c->last_rounds = 1;
+        c->last_rounds = 1; c->last_path = 3;
         HIP_OK(hipStreamSynchronize(stream));
         return ZR_OK;
     }
+    c->last_path = 2;
     if ((rc = ensure_stack_slabs(c, s))) return rc;
     // slot pool: large enough to fill the chip every round, small enough that the frame takes dozens of rounds (a
     // rank that owns 1/8 of the tiles must not degenerate into one shrinking batch)
@@ -1974,6 +1979,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
                              "or a scene with more than 2^24 primitives of a kind): rendered by the pixel-group kernel — same results, about six times slower\n",
                      dc.max_depth, (unsigned long long)stream_units, plan.W, plan.H);
     }
+    c->last_path = 0;
     // one launch per frame unless the caller wants progress / cancellation, which need batch boundaries
     const bool interactive = keep_going || rows_done;
     const int batch = std::max(1, (int)env_double("ZR_BATCH_TILES", interactive ? 256 : (double)(1 << 30)));
@@ -2286,7 +2292,7 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
     if (rc) return rc;
     std::memset(out, 0, sizeof *out);
     out->kernel_ms = c->last_render_ms;
-    out->extend_ms = c->last_extend_ms; out->shade_ms = c->last_shade_ms; out->rounds = c->last_rounds;
+    out->extend_ms = c->last_extend_ms; out->shade_ms = c->last_shade_ms; out->rounds = c->last_rounds; out->path = (uint64_t)c->last_path;
     unsigned long long h[16];
     HIP_OK(hipMemcpy(h, c->d_ctr.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[15] != 0) return fail(ZR_E_DEVICE, "render kernel hit its iteration cap on %llu task(s): results are incomplete", h[15]);

@@ -5,6 +5,8 @@
 // the same call the reference's main.cpp:1520-1521 makes.
 #include <unistd.h>
 
+#include <thread>
+
 #include "../../include/zenith/zenith.hpp"
 
 static void zr_hook_seed_scene(uint64_t seed, uint64_t stream) { zenith::seed_rng(seed, ZR_SCENE_PIXEL, stream); }
@@ -77,6 +79,18 @@ int zrs_render_dropin(void* p, int width, int height, int spp, int device, doubl
     std::memcpy(out, cam.render_accumulator.data(), cam.render_accumulator.size() * sizeof(color));
     if (ctr) *ctr = cam.last_counters;
     return 0;
+}
+
+// The reference starts a fresh thread for every render (main.cpp:1520-1531): `n` renders of the scene, each on a thread of its own,
+// one after the other.  Returns the number of device contexts the process has created so far (the drop-in keeps them in a
+// process-wide pool: successive threads share one), or -1 if a render failed; `out` receives the last frame.
+int zrs_render_dropin_threads(void* p, int width, int height, int spp, int device, int n, double* out) {
+    int rc = 0;
+    for (int k = 0; k < n && rc == 0; k++) {
+        std::thread t([&]() { rc = zrs_render_dropin(p, width, height, spp, device, out, nullptr); });
+        t.join();
+    }
+    return rc == 0 ? (int)zenith::contexts_created() : -1;
 }
 
 // The reference's whole frame pipeline through the drop-in API: render with auto-exposure and the reflection / refraction

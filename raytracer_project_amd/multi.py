@@ -16,7 +16,9 @@ halve 6 MB of traffic that is already negligible and cost the bit-exactness.
 (bench.py); this module contains no rendering arithmetic."""
 import os
 
-TILE = 32
+# side of the interleaved pixel tiles (tile t -> rank t % world).  32 is the library's default tile; ZR_MULTI_TILE overrides it for
+# experiments (larger tiles keep a rank's rays closer together, at the price of coarser load balance)
+TILE = int(os.environ.get("ZR_MULTI_TILE", "32"))
 
 
 def tile_region(capi, rank, world, tile=TILE):
