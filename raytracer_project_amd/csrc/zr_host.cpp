@@ -187,6 +187,8 @@ struct zr_scene {
     int leaf_level = 2;           // EXTEND build: 0 bare triangles / spheres only, 1 + bare and placed cubes and unwrapped media, 2 everything
     uint32_t stack_demand = 0;    // worst-case entries on an EXTEND lane's traversal stack (Flattener::stack_demand)
     size_t leaf_objects = 0;      // leaf objects of the world's tree (all kinds): small worlds render through the fused kernel
+    zr::FusedObjs fused{};        // ... their records, for the kernel arguments (finish_commit)
+    bool fused_ok = false;
     uint64_t stats[4] = {0, 0, 0, 0};
     const char* builder = "";   // which builder made the committed tree (zr_scene_builder)
 };
@@ -1080,6 +1082,35 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
     d.root = cs.root;
     s->leaf_objects = 0;
     for (int k = 0; k < 8; k++) { d.leaf_cnt[k] = cs.leaf_cnt[k]; s->leaf_objects += cs.leaf_cnt[k]; }
+    // a small world's objects for the fused kernel's arguments (zr_launch.h: FusedObjs): read back from the arrays just built,
+    // whichever builder made them (a few hundred bytes)
+    s->fused_ok = false;
+    if (s->leaf_objects > 0 && s->leaf_objects <= ZR_FUSED_OBJECTS && cs.leaf_cnt[ZR_KIND_INSTANCE] == 0) {
+        zr::FusedObjs fo{};
+        auto take = [&](uint32_t kind, const double* d_src, size_t stride, size_t doubles) -> int {
+            for (uint32_t i = 0; i < cs.leaf_cnt[kind]; i++) {
+                fo.kind[fo.n] = kind; fo.index[fo.n] = i;
+                HIP_OK(hipMemcpy(fo.rec[fo.n], d_src + (size_t)i * stride, doubles * sizeof(double), hipMemcpyDeviceToHost));
+                fo.n++;
+            }
+            return ZR_OK;
+        };
+        if ((rc = take(ZR_PRIM_SPHERE, s->d_spheres.p, 4, 4)) || (rc = take(ZR_PRIM_TRIANGLE, s->d_tri_v.p, ZR_TRI_STRIDE, 9)) ||
+            (rc = take(ZR_PRIM_CUBE, s->d_cubes.p, 6, 6)) || (rc = take(ZR_KIND_PCUBE, s->d_pcubes.p, 12, 12))) return rc;
+        std::vector<zr::DMedium> hm(cs.leaf_cnt[ZR_PRIM_MEDIUM]);
+        if (!hm.empty()) HIP_OK(hipMemcpy(hm.data(), s->d_media.p, hm.size() * sizeof(zr::DMedium), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < hm.size(); i++) {
+            if (hm[i].chain_count != 0) continue;   // a wrapped boundary: tested through the scene's arrays (level 2)
+            fo.kind[fo.n] = ZR_PRIM_MEDIUM; fo.index[fo.n] = i;
+            const bool sph = hm[i].btype == ZR_PRIM_SPHERE;
+            HIP_OK(hipMemcpy(fo.rec[fo.n], sph ? s->d_spheres.p + (size_t)hm[i].bindex * 4 : s->d_cubes.p + (size_t)hm[i].bindex * 6, (sph ? 4 : 6) * sizeof(double), hipMemcpyDeviceToHost));
+            fo.rec[fo.n][6] = hm[i].neg_inv_density;
+            const uint64_t idb = hm[i].id, tb = hm[i].btype;
+            std::memcpy(&fo.rec[fo.n][7], &idb, 8); std::memcpy(&fo.rec[fo.n][8], &tb, 8);
+            fo.n++;
+        }
+        s->fused = fo; s->fused_ok = true;
+    }
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         if (cs.n_insts) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
         else if (cs.n_wrapped || !cs.plain_media) s->leaf_level = 2;
@@ -1869,12 +1900,12 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     // segment, the path in registers, no tree, no slot pool.  Testing all objects costs time in proportion to their number, the
     // pipeline about the same per segment whatever the scene: the switch-over is ZR_FUSED_MAX objects.  Callers that poll
     // (cancellation, live preview) and the split passes stay on the pipeline, which has round boundaries to poll at.
-    if (mode == 0 && !keep_going && !progress && s->leaf_level <= 2 && s->leaf_objects > 0 && (double)s->leaf_objects <= env_double("ZR_FUSED_MAX", 16) &&
+    if (mode == 0 && !keep_going && !progress && s->fused_ok && s->leaf_level <= 2 && s->leaf_objects > 0 && (double)s->leaf_objects <= env_double("ZR_FUSED_MAX", ZR_FUSED_OBJECTS) &&
         env_double("ZR_FUSED", 1) != 0) {
         if (c->fused_blocks == 0) c->fused_blocks = zr::fused_blocks();
         HostTimer ftimer(c);
         hipError_t fe = zr::fused_render_frame(s->ds, dc, de, seed, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p, c->fused_blocks, d_out, c->d_ctr.p, count != 0,
-                                               s->leaf_level <= 1 ? 1 : 2, stream, &ftimer);
+                                               s->leaf_level <= 1 ? 1 : 2, stream, &ftimer, s->fused);
         if (fe != hipSuccess) return fail(ZR_E_DEVICE, "fused small-scene kernel failed: %s", hipGetErrorString(fe));
         c->last_rounds = 1; c->last_path = 3;
         HIP_OK(hipStreamSynchronize(stream));

@@ -49,9 +49,23 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
                          unsigned int* h_active, volatile const uint8_t* keep_going, int* rounds_out, int leaf_level, int mode = 0, void* d_kend = nullptr,
                          void* d_cls = nullptr, double* out2 = nullptr, unsigned long long* d_cpart = nullptr, StreamProgress* progress = nullptr,
                          void* drain_pool = nullptr, uint32_t drain_slots = 0, uint32_t unit_chunk = 0);
+// The objects of a small world as the fused kernel wants them: IN THE KERNEL ARGUMENTS.  The kernarg segment is read with scalar
+// loads, so an object's record reaches every lane of a wave through SGPRs — no vector memory instruction, no VGPRs per lane for
+// data that is the same in all of them (reading the records through the scene's pointers, the compiler issued 255 vector loads
+// in the loop and spilled; the pointers come out of a struct, so it cannot prove the addresses uniform and read-only).
+// rec: sphere cx cy cz r | triangle 9 vertices | cube 6 | placed cube 12 | plain medium: boundary (sphere 4 / cube 6), [6] = -1/density,
+// [7] = id bits, [8] = boundary type bits.
+#define ZR_FUSED_OBJECTS 16
+struct FusedObjs {
+    uint32_t n, pad_;
+    uint32_t kind[ZR_FUSED_OBJECTS];    // leaf kind (ZR_PRIM_* / ZR_KIND_PCUBE); media here are plain ones only
+    uint32_t index[ZR_FUSED_OBJECTS];   // index in that kind's array (what a hit reports)
+    double rec[ZR_FUSED_OBJECTS][12];
+};
 int fused_blocks();
 hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
-                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer);
+                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer,
+                              const FusedObjs& objs);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
                         void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, int leaf_level,
                         hipStream_t stream);

@@ -751,38 +751,63 @@ struct FusedBuf {
     const uint32_t* pixels; double* samples; unsigned int* uctl;   // uctl[32 s]: chunk counter of shard s
     uint32_t spp, n_units;
 };
+// plain medium from a kernel-argument record (medium_plain_t's arithmetic: constant_medium.hpp:39-77 on a bare boundary)
+__device__ __forceinline__ bool medium_rec_t(const double* q, const Ray& r, double tmin, double tmax, const Rng& g, double& t) {
+    double t1, t2;
+    const double inf = __builtin_huge_val();
+    const uint32_t btype = (uint32_t)__double_as_longlong(q[8]);
+    if (btype == ZR_PRIM_SPHERE) {
+        if (!sphere_t(q, r, -inf, inf, t1)) return false;
+        if (!sphere_t(q, r, t1 + 0.0001, inf, t2)) return false;
+    } else {
+        if (!cube_t(q, r, -inf, inf, t1)) return false;
+        if (!cube_t(q, r, t1 + 0.0001, inf, t2)) return false;
+    }
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    const double rl = len(r.d);
+    const double inside = (t2 - t1) * rl;
+    const double xi = zr_bits_to_unit(zr_medium_bits(g.key, g.bounce, (uint32_t)__double_as_longlong(q[7])));
+    const double hd = q[6] * log(xi);
+    if (hd > inside) return false;
+    t = t1 + hd / rl;
+    return true;
+}
 template <int LEVEL, bool COUNT>
-__device__ __forceinline__ void brute_hit(const DScene& sc, const Ray& ray, const Rng& g, double& tbest, uint32_t& kbest, uint32_t& ibest, uint32_t* cn) {
+__device__ __forceinline__ void brute_hit(const DScene& sc, const FusedObjs& fo, const Ray& ray, const Rng& g, double& tbest, uint32_t& kbest, uint32_t& ibest, uint32_t* cn) {
     const double INF = __builtin_huge_val();
     tbest = INF; kbest = 0xFFFFFFFFu; ibest = 0;
     double t;
-    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_SPHERE]; i++)
-        if (sphere_t(sc.spheres + (size_t)i * 4, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_SPHERE; ibest = i; }
-    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_TRIANGLE]; i++)
-        if (triangle_t(sc.tri_v + (size_t)i * ZR_TRI_STRIDE, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_TRIANGLE; ibest = i; }
-    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_CUBE]; i++)
-        if (cube_t(sc.cubes + (size_t)i * 6, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_PRIM_CUBE; ibest = i; }
-    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_PCUBE]; i++)
-        if (pcube_t(sc.pcubes + (size_t)i * 12, ray, 0.001, tbest, t)) { tbest = t; kbest = ZR_KIND_PCUBE; ibest = i; }
-    for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_MEDIUM]; i++) {
-        const bool h = LEVEL == 1 ? medium_plain_t(sc, i, ray, 0.001, tbest, g, t) : medium_t(sc, i, ray, 0.001, tbest, g, t);
-        if (h) { tbest = t; kbest = ZR_PRIM_MEDIUM; ibest = i; }
+    // the table's objects: wave-uniform loop counter and kind, records through scalar loads
+    for (uint32_t i = 0; i < fo.n; i++) {
+        const uint32_t k = fo.kind[i];
+        const double* q = fo.rec[i];
+        bool h;
+        if (k == ZR_PRIM_SPHERE) h = sphere_t(q, ray, 0.001, tbest, t);
+        else if (k == ZR_PRIM_TRIANGLE) h = triangle_t(q, ray, 0.001, tbest, t);
+        else if (k == ZR_PRIM_CUBE) h = cube_t(q, ray, 0.001, tbest, t);
+        else if (k == ZR_KIND_PCUBE) h = pcube_t(q, ray, 0.001, tbest, t);
+        else h = medium_rec_t(q, ray, 0.001, tbest, g, t);
+        if (h) { tbest = t; kbest = k; ibest = fo.index[i]; }
+        if (COUNT) { if (k == ZR_PRIM_SPHERE) cn[0]++; else if (k == ZR_PRIM_TRIANGLE) cn[1]++; else if (k == ZR_PRIM_CUBE || k == ZR_KIND_PCUBE) cn[2]++; else cn[3]++; }
     }
-    if (LEVEL >= 2)
-        for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_WRAPPED]; i++)
+    if (LEVEL >= 2) {   // what the table cannot hold: media with a wrapped boundary, objects under wrapper chains (the op-list interpreter)
+        for (uint32_t i = 0; i < sc.leaf_cnt[ZR_PRIM_MEDIUM]; i++) {
+            if (sc.media[i].chain_count == 0) continue;   // (plain ones are in the table)
+            if (medium_t(sc, i, ray, 0.001, tbest, g, t)) { tbest = t; kbest = ZR_PRIM_MEDIUM; ibest = i; }
+            if (COUNT) cn[3]++;
+        }
+        for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_WRAPPED]; i++) {
             if (object_t(sc, ZR_KIND_WRAPPED, i, ray, 0.001, tbest, g, t)) { tbest = t; kbest = ZR_KIND_WRAPPED; ibest = i; }
-    if (COUNT) {
-        cn[0] += sc.leaf_cnt[ZR_PRIM_SPHERE]; cn[1] += sc.leaf_cnt[ZR_PRIM_TRIANGLE]; cn[2] += sc.leaf_cnt[ZR_PRIM_CUBE] + sc.leaf_cnt[ZR_KIND_PCUBE]; cn[3] += sc.leaf_cnt[ZR_PRIM_MEDIUM];
-        if (LEVEL >= 2)
-            for (uint32_t i = 0; i < sc.leaf_cnt[ZR_KIND_WRAPPED]; i++) {
-                const uint32_t kk = sc.wrapped[i].type;
-                if (kk == ZR_PRIM_SPHERE) cn[0]++; else if (kk == ZR_PRIM_TRIANGLE) cn[1]++; else if (kk == ZR_PRIM_CUBE) cn[2]++; else cn[3]++;
-            }
+            if (COUNT) { const uint32_t kk = sc.wrapped[i].type; if (kk == ZR_PRIM_SPHERE) cn[0]++; else if (kk == ZR_PRIM_TRIANGLE) cn[1]++; else if (kk == ZR_PRIM_CUBE) cn[2]++; else cn[3]++; }
+        }
     }
 }
 
 template <int LEVEL, bool COUNT>
-__global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, DCamera cam, DEnv env, uint64_t seed, FusedBuf B, unsigned long long* __restrict__ gctr) {
+__global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, DCamera cam, DEnv env, uint64_t seed, FusedBuf B, unsigned long long* __restrict__ gctr, FusedObjs fo) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -840,7 +865,7 @@ __global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, D
         if (__ballot(active) == 0ull) { if (!units_left) break; else continue; }
         // ---- one segment for every active lane: closest hit over all leaf objects, then the shading of the winner
         double t_hit; uint32_t kind, idx;
-        brute_hit<LEVEL, COUNT>(sc, ray, g, t_hit, kind, idx, cn);
+        brute_hit<LEVEL, COUNT>(sc, fo, ray, g, t_hit, kind, idx, cn);
         if (active) {
             g.bounce++;
             if (COUNT) { c_seg++; if (kind != NONE) c_hit++; }
@@ -1209,7 +1234,8 @@ int fused_blocks() {
     return cus * per_cu;
 }
 hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
-                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer) {
+                              unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer,
+                              const FusedObjs& fo) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     hipError_t e;
@@ -1219,8 +1245,8 @@ hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& 
     unsigned long long want_blocks = (n_chunks + 3) / 4;   // no more waves than chunks
     const dim3 grid((unsigned)(want_blocks < (unsigned long long)blocks ? (want_blocks ? want_blocks : 1) : blocks)), block(256);
     if (timer) timer->begin(stream, 1);
-    if (level <= 1) { if (count) hipLaunchKernelGGL((fused_render<1, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); else hipLaunchKernelGGL((fused_render<1, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); }
-    else { if (count) hipLaunchKernelGGL((fused_render<2, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); else hipLaunchKernelGGL((fused_render<2, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr); }
+    if (level <= 1) { if (count) hipLaunchKernelGGL((fused_render<1, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<1, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
+    else { if (count) hipLaunchKernelGGL((fused_render<2, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<2, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
     if (timer) timer->end(stream, 1);
     StreamBuf R = make_buf(nullptr, 0, spp, n_units, n_pix, d_pixels, d_samples, d_ctl, d_ctl, 0, 0);
     if (timer) timer->begin(stream, 3);
