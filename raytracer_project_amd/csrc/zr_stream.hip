@@ -43,9 +43,19 @@ namespace zr {
 #ifndef ST_FETCH_MIN
 #define ST_FETCH_MIN 16  /* idle lanes that trigger a refill even when another phase has more ready lanes */
 #endif
+#ifndef ST_LEAF_ONE_KIND
+#define ST_LEAF_ALL 1   /* a LEAF iteration serves EVERY leaf kind that has waiting lanes, kind by kind under wave-uniform guards (round 3), instead of only
+                           the kind with most lanes: the few lanes at the other kind (cfg3: the ground sphere every ray meets) no longer sit out NODE
+                           iterations waiting for company.  cfg3 EXTEND 213.1 -> 204.6 ms per frame with the 1:1 bias below (2:3: 206.2; the old
+                           one-kind rule with its 1:2 bias: 213.1), cfg2 46.7 -> 46.2; image bit-identical (profiles/r3_experiments_ab.txt) */
+#endif
 #ifndef ST_BIAS_NODE
-#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF; favouring LEAF 2:1 is 3 % faster on cfg3 (a tested leaf shrinks tbest and culls the stack), 1:1 and 3:1 are slower */
-#define ST_BIAS_LEAF 2
+#define ST_BIAS_NODE 1  /* NODE runs when ready NODE lanes x ST_BIAS_NODE >= ready LEAF lanes x ST_BIAS_LEAF (LEAF lanes = all kinds together with ST_LEAF_ALL) */
+#ifdef ST_LEAF_ALL
+#define ST_BIAS_LEAF 1
+#else
+#define ST_BIAS_LEAF 2  /* one kind per LEAF iteration: favouring LEAF 2:1 was 3 % faster on cfg3 than 1:1 (a tested leaf shrinks tbest and culls the stack) */
+#endif
 #endif
 #define ST_SHARDS 64     /* unit counters (ctl[16 + 32 * s]): a single contended word sustains only ~90 atomics/us */
 #ifndef ST_LDS_STACK
@@ -293,7 +303,11 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
         const int n2s = __popcll(__ballot(st == X_LEAF && lkind == ZR_PRIM_SPHERE));
         const int n2g = LEVEL > 0 ? __popcll(__ballot(st == X_LEAF)) - n2t - n2s : 0;
         const int n0 = work_left ? __popcll(__ballot(st == X_IDLE)) : 0;
+#ifdef ST_LEAF_ALL
+        const int n2 = n2t + n2s + n2g;
+#else
         const int n2 = n2t > n2s ? (n2t > n2g ? n2t : n2g) : (n2s > n2g ? n2s : n2g);
+#endif
         if (n1 + n2 + n0 == 0) break;
 
         if (n0 >= ST_FETCH_MIN || (n0 > 0 && n0 >= n1 && n0 >= n2)) {
@@ -390,8 +404,15 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
             p_exec[1]++; p_lanes[1] += n2;
 #endif
             const bool is_leaf = st == X_LEAF;
+#ifdef ST_LEAF_ALL
+            // experiment: every leaf kind that has waiting lanes is served in this iteration (kind by kind, each under a wave-uniform
+            // guard) instead of only the kind with most lanes
+            const bool do_tri = n2t > 0;
+            const bool do_sph = n2s > 0;
+#else
             const bool do_tri = n2t == n2;
             const bool do_sph = !do_tri && n2s == n2;
+#endif
             const uint32_t prim = (cur & 0xFFFFFFu) + pend_i;
             bool tested = false;
             if (do_tri) {
@@ -404,14 +425,24 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                     }
                     tested = true;
                 }
-            } else if (do_sph) {
+            }
+#ifdef ST_LEAF_ALL
+            if (do_sph) {
+#else
+            else if (do_sph) {
+#endif
                 if (is_leaf && lkind == ZR_PRIM_SPHERE) {
                     double t;
                     if (COUNT) c_sph++;
                     if (sphere_t(sc.spheres + (size_t)prim * 4, ray, 0.001, tbest, t)) { tbest = t; tbest_f = __double2float_ru(t); kbest = lkind; ibest = prim; }
                     tested = true;
                 }
-            } else if (LEVEL > 0 && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+            }
+#ifdef ST_LEAF_ALL
+            if (LEVEL > 0 && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+#else
+            else if (LEVEL > 0 && is_leaf && lkind != ZR_PRIM_TRIANGLE && lkind != ZR_PRIM_SPHERE) {
+#endif
                 double t;
                 if (COUNT && lkind < ZR_KIND_INSTANCE) {
                     uint32_t kk = lkind;
