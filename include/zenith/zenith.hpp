@@ -253,38 +253,40 @@ public:
 
     void unsupported(const char* what) { fs.warnings.push_back(std::string("unsupported hittable skipped: ") + what); }
 
-    // TWO-LEVEL BVH.  A mesh (model, bvh_node of triangles) that sits under wrappers is what the reference shares between
-    // instances (the same shared_ptr in several translate / rotate_* / scale / material_instance objects): its triangles are
-    // flattened ONCE, in their own space, as a zr_group, and every placement becomes one ZR_PRIM_GROUP object carrying the
-    // wrapper chain.  `children` flattens the child's parts.  A child that turns out not to be bare triangles, or that is placed
-    // only once (finish()), is flattened the plain way: one entry per triangle, each with the chain.
+    // TWO-LEVEL BVH.  What the reference shares between instances — the same shared_ptr (a model, a bvh_node, a prefab list) inside
+    // several translate / rotate_* / scale / material_instance objects — is flattened ONCE, in its own space, into a TEMPLATE:
+    //   * its runs of bare triangles become zr_groups (stored once, a tree of their own on the device; every placement of the run
+    //     is ONE ZR_PRIM_GROUP world entry carrying the wrapper chain),
+    //   * its other members — spheres, cubes, media, primitives under wrappers of their own inside the child — are stored once
+    //     too and referenced by index: a placement emits one world entry per member whose chain is the placement's followed by
+    //     the member's inner chain,
+    //   * a shared child INSIDE the child (a group inside a group) is a template of its own, referenced under its inner chain:
+    //     its triangle runs are the same zr_groups wherever the outer child is placed.
+    // So a composite prefab placed N times costs N small entries per member and per mesh, and its triangles once (round 2 shared
+    // only children that were nothing but bare triangles; anything else was copied per placement, triangles included).
+    // `children` flattens the child's parts.  A run placed only once in the end is dissolved by finish().
     template <class F>
     void emit_run(const void* identity, F&& children) {
         const char* e_ = std::getenv("ZR_GROUPS");
-        const bool off = e_ && *e_ == '0';   // ZR_GROUPS=0: always one entry per triangle
-        if (off || chain.empty() || in_boundary || in_run) { children(); return; }
-        auto it = run_ids.find(identity);
-        if (it == run_ids.end()) {
-            std::vector<zr_xform_op> outer; outer.swap(chain);
-            const size_t first = fs.tri_mat.size(), n_sph = fs.sphere_mat.size(), n_cube = fs.cube_mat.size(), n_med = fs.media.size(), n_ops = fs.ops.size();
-            in_run = true; run_ok = true;
+        const bool off = e_ && *e_ == '0';   // ZR_GROUPS=0: always one entry per primitive
+        if (off || in_boundary || (caps.empty() && chain.empty())) { children(); return; }   // (a child added bare to the world is flattened in place)
+        auto it = tmpl_ids.find(identity);
+        if (it == tmpl_ids.end()) {
+            const uint32_t id = (uint32_t)templates.size();
+            templates.emplace_back();
+            caps.push_back(capture{id, chain.size()});
             children();
-            in_run = false; chain.swap(outer);
-            const size_t n = fs.tri_mat.size() - first;
-            if (!run_ok || n == 0) {   // not a run of bare triangles: forget everything the capture appended and flatten the child in place
-                fs.tri_v.resize(first * 9); fs.tri_n.resize(first * 9); fs.tri_mat.resize(first);
-                fs.spheres.resize(n_sph * 4); fs.sphere_mat.resize(n_sph); fs.cubes.resize(n_cube * 12); fs.cube_mat.resize(n_cube);
-                fs.media.resize(n_med); fs.ops.resize(n_ops);
-                run_ids[identity] = 0xFFFFFFFFu;
-                children();
-                return;
-            }
-            zr_group g{}; g.first_triangle = (uint32_t)first; g.triangle_count = (uint32_t)n;
-            fs.groups.push_back(g);
-            it = run_ids.emplace(identity, (uint32_t)fs.groups.size() - 1).first;
+            caps.pop_back();
+            close_template(id);
+            it = tmpl_ids.emplace(identity, id).first;
         }
-        if (it->second == 0xFFFFFFFFu) { children(); return; }
-        emit(ZR_PRIM_GROUP, it->second);
+        if (!caps.empty()) {   // met while an outer child is being captured: a member of that template, under the chain opened since
+            tmpl_item m; m.what = 2; m.index = it->second;
+            m.inner.assign(chain.begin() + (std::ptrdiff_t)caps.back().base, chain.end());
+            templates[caps.back().tmpl].items.push_back(std::move(m));
+            return;
+        }
+        expand(it->second);
     }
     // call once, after the world has been flattened and before flat_scene::desc(): groups placed a single time gain nothing from
     // a tree of their own — their placement is replaced by its triangles (each under the placement's chain) unless
@@ -316,13 +318,49 @@ private:
     bool in_boundary = false;
     zr_object captured{};            // the boundary primitive of the medium being flattened
     bool captured_ok = false;
-    bool in_run = false, run_ok = true;   // capturing a group's triangles (emit_run)
-    std::unordered_map<const void*, uint32_t> run_ids;   // child object -> its group (0xFFFFFFFF: not a run)
+    // templates of shared children (emit_run)
+    struct tmpl_item { int what = 1; /* 0 run of triangles -> group, 1 primitive, 2 another template */ uint32_t type = 0, index = 0, count = 0; std::vector<zr_xform_op> inner; };
+    struct tmpl { std::vector<tmpl_item> items; };
+    struct capture { uint32_t tmpl; size_t base; /* chain.size() when the capture began: what follows is the member's inner chain */ };
+    std::vector<tmpl> templates;
+    std::vector<capture> caps;
+    std::unordered_map<const void*, uint32_t> tmpl_ids;   // shared child -> its template
     std::unordered_map<const material*, uint32_t> mat_ids;
     std::unordered_map<const texture*, uint32_t> tex_ids;
 public:
     std::unordered_map<uint32_t, shared_ptr<material>> mat_ptrs;   // flattened material id -> the object it came from
 private:
+    // a captured child is complete: its triangle runs become groups (a run shorter than ZR_GROUP_MIN_TRIS, default 4, beside other
+    // members is not worth a tree of its own: it stays a list of triangles)
+    void close_template(uint32_t id) {
+        tmpl& t = templates[id];
+        const char* e = std::getenv("ZR_GROUP_MIN_TRIS");
+        const uint32_t min_tris = e && *e ? (uint32_t)std::atoi(e) : 4u;
+        const bool pure = t.items.size() == 1 && t.items[0].what == 0;   // nothing but one run of triangles (a model): always a group
+        std::vector<tmpl_item> out;
+        for (tmpl_item& m : t.items) {
+            if (m.what != 0) { out.push_back(std::move(m)); continue; }
+            if (pure || m.count >= min_tris) {
+                zr_group g{}; g.first_triangle = m.index; g.triangle_count = m.count;
+                fs.groups.push_back(g);
+                m.index = (uint32_t)fs.groups.size() - 1;
+                out.push_back(std::move(m));
+            } else
+                for (uint32_t k = 0; k < m.count; k++) { tmpl_item q; q.what = 1; q.type = ZR_PRIM_TRIANGLE; q.index = m.index + k; out.push_back(std::move(q)); }
+        }
+        t.items.swap(out);
+    }
+    // one placement of a template under the chain that is open now
+    void expand(uint32_t id) {
+        for (size_t k = 0; k < templates[id].items.size(); k++) {
+            const tmpl_item m = templates[id].items[k];   // (a copy: emit() below may grow `templates`' neighbours, never this vector, but stay safe)
+            for (const zr_xform_op& op : m.inner) chain.push_back(op);
+            if (m.what == 0) emit(ZR_PRIM_GROUP, m.index);
+            else if (m.what == 1) emit(m.type, m.index);
+            else expand(m.index);
+            chain.resize(chain.size() - m.inner.size());
+        }
+    }
 
     uint32_t copy_chain(size_t from, size_t to) {
         uint32_t first = (uint32_t)fs.ops.size();
@@ -332,8 +370,18 @@ private:
     void emit(uint32_t type, uint32_t index) {
         zr_object o{};
         o.type = type; o.index = index;
-        if (in_run && (type != ZR_PRIM_TRIANGLE || !chain.empty() || in_boundary)) run_ok = false;   // only bare triangles make a group
-        if (in_run && !in_boundary) return;   // a group's own triangle is not a world-list entry
+        if (!caps.empty() && !in_boundary) {   // inside a shared child that is being captured: a member of its template, not a world entry
+            tmpl& t = templates[caps.back().tmpl];
+            const size_t base = caps.back().base;
+            if (type == ZR_PRIM_TRIANGLE && chain.size() == base && !t.items.empty() && t.items.back().what == 0 &&
+                t.items.back().index + t.items.back().count == index) { t.items.back().count++; return; }   // the run goes on
+            tmpl_item m;
+            m.what = (type == ZR_PRIM_TRIANGLE && chain.size() == base) ? 0 : 1;
+            m.type = type; m.index = index; m.count = 1;
+            m.inner.assign(chain.begin() + (std::ptrdiff_t)base, chain.end());
+            t.items.push_back(std::move(m));
+            return;
+        }
         if (in_boundary) {
             o.chain_count = (uint32_t)(chain.size() - boundary_base);
             o.chain_first = copy_chain(boundary_base, chain.size());

@@ -84,7 +84,14 @@ public:
         zr_oracle_tls.bounce = (uint32_t)seg_in_sample();
         seg_tls.segments++;
         sample_segments()++;
-        return w.hit(r, ray_t, rec, depth, debug_wire);
+        const bool h = w.hit(r, ray_t, rec, depth, debug_wire);
+        // diagnostic (ZR_REF_TRACE=1 with a one-pixel tile): every closest-hit query of the genuine code, as it happens
+        static const bool trace = std::getenv("ZR_REF_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[ref] seg %llu draws %llu o %.17g %.17g %.17g d %.17g %.17g %.17g -> hit %d t %.17g p %.9g %.9g %.9g n %.6g %.6g %.6g\n",
+                                (unsigned long long)sample_segments(), (unsigned long long)zr_oracle_tls.k, r.origin().x(), r.origin().y(), r.origin().z(), r.direction().x(),
+                                r.direction().y(), r.direction().z(), (int)h, h ? rec.t : 0.0, h ? rec.p.x() : 0.0, h ? rec.p.y() : 0.0, h ? rec.p.z() : 0.0,
+                                h ? rec.normal.x() : 0.0, h ? rec.normal.y() : 0.0, h ? rec.normal.z() : 0.0);
+        return h;
     }
     aabb bounding_box() const override { return w.bounding_box(); }
     static uint64_t& sample_segments() { static thread_local uint64_t n = 0; return n; }
@@ -212,7 +219,7 @@ struct built_scene {
 
 static bool build(built_scene& b, const std::string& name, int a0, int a1, int a2, int a3) {
     g_next_medium_id = 0;
-    bool ok = zr_build_scene(name, b.s, a0, a1, a2, a3) || zr_build_scene_mix(name, b.s);
+    bool ok = zr_build_scene(name, b.s, a0, a1, a2, a3) || zr_build_scene_mix(name, b.s, a0);
     if (!ok && name == "refdemo") { zr_build_refdemo(b.s); ok = true; }   // needs the reference's assets/ tree in the working directory
     if (!ok) return false;
     // bvh_node's constructor draws random_int(0,2) per node (bvh.hpp:17): give it its own scene stream

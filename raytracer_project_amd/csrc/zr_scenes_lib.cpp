@@ -30,7 +30,7 @@ extern "C" {
 
 void* zrs_build(const char* name, int a0, int a1, int a2, int a3) {
     handle* h = new handle();
-    bool ok = zr_build_scene(name, h->s, a0, a1, a2, a3) || zr_build_scene_mix(name, h->s);
+    bool ok = zr_build_scene(name, h->s, a0, a1, a2, a3) || zr_build_scene_mix(name, h->s, a0);
     if (!ok) { delete h; return nullptr; }
     zenith::scene_builder b(h->fs);
     h->s.world.flatten(b);

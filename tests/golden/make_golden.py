@@ -37,6 +37,7 @@ TILES = {
     "mix0_tile": ("mix0", 30, 20, 16, 16, 0, True, []),
     "mesh0_full": ("mesh0", 0, 0, 96, 64, 0, False, []),            # OBJ ingest through `model`
     "inst1_full": ("inst1", 0, 0, 112, 72, 0, False, []),           # grouping corner cases: mixed shared child, nested wrappers, bare + placed, single placement
+    "inst2_full": ("inst2", 0, 0, 128, 80, 0, False, []),           # a composite prefab x 6 (mesh inside the prefab: a group inside a group, sphere, placed cube, pedestal) + the mesh by itself
     "inst0_full": ("inst0", 0, 0, 128, 80, 0, False, []),           # one mesh placed 36 times + one placed 8 times (two-level BVH on the device)
     # the reference's own demo workload (scene_management.hpp:103-236): 900 instanced prefabs, a wrapped mesh, fog
     "demo_tile": ("demo", 560, 300, 48, 32, 32, False, []),          # mesh + mirror sphere + glass cube
@@ -52,6 +53,7 @@ TRACES = {
     "trace_mesh0": ("mesh0", 4096, 15, -3, 4, []),
     "trace_inst0": ("inst0", 4096, 18, -7, 7, []),
     "trace_inst1": ("inst1", 4096, 19, -5, 5, []),
+    "trace_inst2": ("inst2", 4096, 24, -6, 6, []),
     "trace_demo": ("demo", 4096, 16, -16, 16, []),
     "trace_cfg3w_small": ("cfg3w", 4096, 17, -4, 4, [200, 20, 256, 128]),   # a placed (wrapped) mesh: baked to world space on the device
     # adversarial rays (ZR_TRACE_ADVERSARIAL: zero direction components, tiny/large scales, round and far origins)
@@ -68,6 +70,7 @@ AOVS = {
     "aov_cfg2": ("cfg2", 560, 280, 48, 32, 20.0, []),
     "aov_mesh0": ("mesh0", 0, 0, 96, 64, 9.0, []),
     "aov_inst0": ("inst0", 0, 0, 128, 80, 25.0, []),
+    "aov_inst2": ("inst2", 0, 0, 128, 80, 25.0, []),
 }
 
 # beauty / reflection / refraction with the split flags on (camera.hpp:490-517): (scene, x0, y0, w, h, spp, scene args)

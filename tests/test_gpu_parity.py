@@ -20,7 +20,7 @@ REL_TOL = 1e-4      # north_star: "within 1e-4 relative per-channel"
 ABS_FLOOR = 1e-7    # radiance below this is treated as 0 for the relative comparison
 
 TILE_FIXTURES = ["cfg1_full", "cfg1_tile", "cfg2_tile", "cfg2_tile_b", "cfg3_small", "cfg3_full", "cfg5_tile",
-                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "inst1_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
+                 "cfg5_tile_b", "mix0_full", "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "inst1_full", "inst2_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
 
 
 @pytest.fixture(scope="module")
@@ -101,7 +101,7 @@ def test_radiance_matches_reference(name, count, builder, ctx):
 
 
 @pytest.mark.parametrize("engine", ["extend", "pairs"])
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_inst1", "trace_demo", "trace_cfg3w_small",
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_inst1", "trace_inst2", "trace_demo", "trace_cfg3w_small",
                                   "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 @pytest.mark.parametrize("builder", BUILDERS)
 def test_hit_records_match_reference(name, engine, builder, ctx, monkeypatch):
@@ -476,6 +476,34 @@ def test_shared_mesh_is_stored_once(built, monkeypatch):
     assert (err > REL_TOL).sum() == 0, float(err.max())
 
 
+def test_composite_prefab_shares_its_triangles(built, monkeypatch):
+    """inst2: a prefab that holds a mesh (itself a shared model under a translate: a group inside a group), a glass sphere, a placed
+    cube and a pedestal of six triangles, placed N times under scale / material_instance / rotate_z / translate; the mesh also
+    placed by itself.  The drop-in flattens the prefab into a template: the triangles are stored once whatever N is (two zr_groups),
+    a placement adds four small world entries; with ZR_GROUPS=0 every placement copies every triangle.  Same picture."""
+    from raytracer_project_amd import capi
+    shapes, sizes, frames = [], [], []
+    for n, groups in ((6, "1"), (18, "1"), (6, "0")):
+        monkeypatch.setenv("ZR_GROUPS", groups)
+        ds = capi.DemoScene("inst2", n)
+        shapes.append((ds.desc.n_objects, ds.desc.n_groups, ds.desc.n_tris))
+        c = capi.Context(0)
+        try:
+            sc = capi.Scene(c, ds.desc)
+            sizes.append(sc.stats()["device_bytes"])
+            if n == 6:
+                frames.append(sc.render(ds.camera, ds.env, ds.seed, None))
+            sc.close()
+        finally:
+            c.close()
+    assert shapes[0] == (1 + 4 * 6 + 3 + 2, 2, 487) and shapes[1] == (1 + 4 * 18 + 3 + 2, 2, 487), shapes   # triangles: independent of N
+    assert shapes[2][1] == 0 and shapes[2][2] == 6 * 486 + 3 * 480 + 1, shapes
+    # three times the placements: a few hundred bytes each (entry, wrapper ops, the placed sphere / cube records), no triangle
+    assert sizes[1] - sizes[0] < 12 * 4 * 1024 and sizes[2] > 4 * sizes[0], sizes
+    err = rel_err(frames[0], frames[1])
+    assert (err > REL_TOL).sum() == 0, float(err.max())
+
+
 def test_bench_line_contract(built):
     """bench.py on the reference's own CPU-sized case: one JSON line with the driver's keys, the roofline object (incl. the
     random-record rate the traversal kernel runs against) and a CPU baseline whose port reproduces the reference's counts."""
@@ -562,7 +590,7 @@ def test_full_size_properties(name, ctx):
         _check(full[m["y0"]:m["y0"] + m["h"], m["x0"]:m["x0"] + m["w"]], fx["mean"], fx_name + " inside the full frame")
 
 
-@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0", "aov_inst0"])
+@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0", "aov_inst0", "aov_inst2"])
 def test_aov_passes_match_reference(name, ctx):
     """zr_render_aov (albedo / camera-space normal / z-depth of the primary hits) vs the genuine reference."""
     from raytracer_project_amd import capi
@@ -606,7 +634,7 @@ def test_reflection_refraction_passes_match_reference(name, ctx):
     _check(b[sl], plain[sl], name + " beauty vs zr_render")
 
 
-@pytest.mark.parametrize("name", ["mix0", "mix1", "mix2", "cfg2", "cfg5", "mesh0", "demo", "inst0", "inst1"])
+@pytest.mark.parametrize("name", ["mix0", "mix1", "mix2", "cfg2", "cfg5", "mesh0", "demo", "inst0", "inst1", "inst2"])
 def test_path_records_match_oracle(name, ctx):
     """zr_trace_paths: every segment of 3000 primary samples — ray, hit, material, scatter decision, attenuation, emission
     and the number of RNG draws consumed — against the CPU oracle walking the same samples.  This is the device-side
@@ -635,7 +663,7 @@ def test_path_records_match_oracle(name, ctx):
 
 
 @pytest.mark.parametrize("variant", [0])
-@pytest.mark.parametrize("name", ["cfg1_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full", "mix1_full", "mesh0_full", "inst0_full", "inst1_full", "demo_tile_b"])
+@pytest.mark.parametrize("name", ["cfg1_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full", "mix1_full", "mesh0_full", "inst0_full", "inst1_full", "inst2_full", "demo_tile_b"])
 def test_other_kernel_variants_match_reference(name, variant, built, monkeypatch):
     """ZR_KERNEL=0, the pixel-group megakernel that renders frames beyond the streaming pipeline's packing limits, shares the device
     arithmetic with the pipeline but walks the pair BVH and integrates in registers: same fixtures, same bar."""

@@ -7,7 +7,7 @@ import pytest
 from conftest import demo_scene, load_golden
 
 TILE_FIXTURES = ["cfg1_full", "cfg1_tile", "cfg2_tile", "cfg2_tile_b", "cfg3_small", "cfg5_tile_b", "mix0_full",
-                 "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "inst1_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
+                 "mix1_full", "mix2_full", "mix0_tile", "mesh0_full", "inst0_full", "inst1_full", "inst2_full", "demo_tile", "demo_tile_b", "cfg3w_small"]
 SLOW_TILE_FIXTURES = ["cfg5_tile"]  # 1024 spp x depth 50: a few seconds
 
 
@@ -42,7 +42,7 @@ def test_oracle_matches_reference_radiance(name, built):
         assert np.array_equal(counts, fx["counts"])
 
 
-@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_inst1", "trace_demo", "trace_cfg3w_small",
+@pytest.mark.parametrize("name", ["trace_mix0", "trace_cfg2", "trace_cfg5", "trace_cfg3_small", "trace_mesh0", "trace_inst0", "trace_inst1", "trace_inst2", "trace_demo", "trace_cfg3w_small",
                                   "trace_adv_mix0", "trace_adv_cfg2", "trace_adv_cfg3_small"])
 def test_oracle_matches_reference_hit_records(name, built):
     """world.hit() known answers: t, p, normal, front_face, u, v, tangent and the first scatter's attenuation."""
@@ -100,7 +100,7 @@ def test_hdr_texels_match_stb_decode(built):
     assert np.array_equal(arr.reshape(32, 64, 3), fx["texels"])
 
 
-@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0", "aov_inst0"])
+@pytest.mark.parametrize("name", ["aov_mix0", "aov_mix1", "aov_cfg2", "aov_mesh0", "aov_inst0", "aov_inst2"])
 def test_oracle_matches_reference_aov(name, built):
     """First-hit albedo / camera-space normal / z-depth passes (camera.hpp:464-488) against the genuine
     material::get_albedo and hit records: bit-identical."""
