@@ -9,8 +9,9 @@ BASELINE.json — the 1 000 000-triangle mesh + HDRI IBL at 1920x1080, 512 spp, 
 configuration the metric's roofline target ("1M-triangle BVH traversal at 1 GPU") and the multi-GPU config (cfg4,
 "same 1M-tri scene pixel-tiled") are quoted on; cfg2 (configs[1]) and cfg5 are selectable with --workload.
 With N > 1 the frame's 32x32 pixel tiles are interleaved over the ranks (scene replicated, weak in memory but the
-total work is fixed => "strong" scaling) and every step ends with one RCCL all-gather of the ranks' packed tiles (1/N of the
-double3 accumulator each), which rank 0 scatters into the frame.
+total work is fixed => "strong" scaling) and every step ends with one RCCL gather of the ranks' packed tiles (1/N of the
+double3 accumulator each) onto rank 0, which scatters them into the frame.  `python bench.py --gpus N` without a launcher starts
+its N ranks itself (fresh child processes through torch.distributed.run, before anything touches the GPU).
 
 The timed region starts with the scene (BVH, vertices, normals, HDRI) resident in HBM and contains: zeroing the
 accumulator, the render kernel(s), the RCCL exchange.  One JSON line is printed by rank 0.

@@ -1228,7 +1228,13 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     for (int k = 0; k < 8; k++) bp.leaf_cap[k] = leaf_cap[k];
     bp.open_ratio = (float)env_double("ZR_BVH_OPEN_RATIO", 1.25);
     bp.radius = (int)env_double("ZR_BVH_PLOC_RADIUS", 16);
-    bp.top_clusters = (int)env_double("ZR_BVH_TOP", 16384);
+    // PLOC stops at n / 16 clusters (4096 ... 65536) and the host's SAH builder arranges those: the larger the SAH-built top, the closer
+    // the walk comes to the host tree's (cfg3 EXTEND per frame: no top +7.8 %, 16384 clusters +2.6 %, 65536 +1.7 % — the whole frame
+    // then equals the host tree's — for 19 / 19 / 28 ms of commit; profiles/r3_builders.txt).  ZR_BVH_TOP overrides (0: PLOC to the root)
+    {
+        const double top_env = env_double("ZR_BVH_TOP", -1);
+        bp.top_clusters = top_env >= 0 ? (int)top_env : (int)std::min<size_t>(65536, std::max<size_t>(4096, (size_t)n / 16));
+    }
     zr::BuildPrimOut out;
     out.spheres = s->d_spheres.p; out.sphere_mat = s->d_sphere_mat.p; out.tri_v = s->d_tri_v.p; out.tri_s = s->d_tri_s.p;
     out.cubes = s->d_cubes.p; out.cube_mat = s->d_cube_mat.p; out.pcubes = s->d_pcubes.p; out.pcube_mat = s->d_pcube_mat.p;
@@ -1576,8 +1582,8 @@ int zr_scene_commit(zr_scene* s) {
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
     {   // which builder.  ZR_BVH_BUILD=device | host forces one; otherwise worlds of at least ZR_BVH_DEVICE_MIN entries (131072: from
         // there on the device build's top is arranged by SAH, zr_build.h) are built on the device: cfg3's 1M triangles commit in
-        // 19 ms instead of 95 and EXTEND walks the tree 2 % slower (cfg3w: 3.5 %) — profiles/r3_builders.txt; a small world is
-        // built faster by the host than a few dozen kernel launches take
+        // 28 ms instead of 109 and the frame takes the same time on either tree (EXTEND alone 1.7 % more) — profiles/r3_builders.txt;
+        // a small world is built faster by the host than a few dozen kernel launches take
         const char* bm = std::getenv("ZR_BVH_BUILD");
         const bool force_dev = bm && std::strcmp(bm, "device") == 0, force_host = bm && std::strcmp(bm, "host") == 0;
         const bool use_dev = !force_host && !objs.empty() && objs.size() < (1u << 30) && (force_dev || (double)objs.size() >= env_double("ZR_BVH_DEVICE_MIN", 131072));

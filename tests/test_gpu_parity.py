@@ -327,7 +327,8 @@ def test_empty_and_degenerate_scenes(ctx):
     _check(out, cpu, "single sphere")
 
 
-def test_deep_tree_sizes_the_traversal_stack(ctx, monkeypatch):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_deep_tree_sizes_the_traversal_stack(builder, ctx, monkeypatch):
     """A world built to need a deep traversal stack: 600 concentric spherical shells, every one a leaf of its own, all of them
     overlapping every ray through the centre.  The committed scene reports its exact worst-case stack demand
     (zr_scene_traversal_stack), the per-wave spill slabs are sized from it, and EXTEND's answers equal the pair walk's and the
@@ -345,7 +346,15 @@ def test_deep_tree_sizes_the_traversal_stack(ctx, monkeypatch):
     d.materials = C.cast(mat, C.c_void_p); d.n_materials = 1
     d.textures = C.cast(tex, C.c_void_p); d.n_textures = 1
     monkeypatch.setenv("ZR_BVH_MAX_LEAF", "1")
+    # through both builders: 600 concentric boxes are the worst case for a bottom-up merger too (every cluster overlaps every
+    # other); should the device tree come out deeper than the traversal stack allows, the commit falls back to the host builder
+    # and says so — either way the answers below must hold
+    monkeypatch.setenv("ZR_BVH_BUILD", builder)
+    monkeypatch.setenv("ZR_BUILD_CHECK", "1")
     sc = capi.Scene(ctx, d)
+    assert sc.stats()["builder"].startswith(("host", "device"))
+    if builder == "host":
+        assert sc.stats()["builder"].startswith("host")
     demand = sc.stats()["traversal_stack"]
     assert demand > 12, demand      # more than the LDS part of the stack: the HBM slab is in use
     rng = np.random.default_rng(3)
