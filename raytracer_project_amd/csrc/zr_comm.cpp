@@ -68,7 +68,7 @@ struct zr_comm {
     // packed-tile exchange: per rank the flat pixel indices (y * W + x, ascending) of the tiles it owns, cached per frame geometry
     int W = 0, H = 0, tile = 0, root_built = 0;
     std::vector<size_t> first, count;     // rank r owns idx[first[r] .. first[r] + count[r])
-    size_t share = 0;                     // max over ranks of count[r]: the all-gather's fixed element count
+    size_t share = 0;                     // max over ranks of count[r]: the stride of the root's receive slots
     uint32_t* d_idx = nullptr; double* d_packed = nullptr; double* d_all = nullptr;
     void release() { if (d_idx) (void)hipFree(d_idx); if (d_packed) (void)hipFree(d_packed); if (d_all) (void)hipFree(d_all); d_idx = nullptr; d_packed = d_all = nullptr; }
 };

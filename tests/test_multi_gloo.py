@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two gloo ranks render interleaved pixel tiles of one frame and exchange them — the default
-packed-tile all-gather and the whole-frame sum-reduce — so that rank 0 holds the frame (raytracer_project_amd/multi.py — the same driver bench.py runs over RCCL).  On CPU the tile
+packed-tile gather onto rank 0 and the whole-frame sum-reduce — so that rank 0 holds the frame (raytracer_project_amd/multi.py — the same driver bench.py runs over RCCL).  On CPU the tile
 renderer is the oracle (test infrastructure); on the GPU box tests/test_gpu_parity.py::test_tile_sharding_is_exact
 covers the device side of the same property.  The reduced frame must equal the single-process frame bit for bit."""
 import os
@@ -48,7 +48,7 @@ import pytest
 @pytest.mark.parametrize("exchange,world,tile", [("gather", 2, 16), ("reduce", 2, 16), ("gather", 3, 20)])
 def test_tile_sharding_gloo(exchange, world, tile, built, tmp_path):
     """(gather, 3 ranks, 20-pixel tiles): 5 x 4 tiles with clipped ones at the right and bottom edges, shares of unequal size —
-    the padded part of the all-gather must not leak into the frame"""
+    the padded part of a share must not leak into the frame"""
     from oracle import zr_oracle_py as zo
     from raytracer_project_amd import capi
     script = tmp_path / "worker.py"
