@@ -32,7 +32,7 @@ struct BuildParams {
     float open_ratio = 1.25f;  // 4-wide collapse: a child is not opened when the wider node's grid would inflate a box's area beyond this
     int radius = 16;           // PLOC search radius (clusters on either side in Morton order)
     int top_clusters = 16384;  // PLOC stops at this many clusters and the host's binned-SAH builder arranges them (0: PLOC to the root); worlds under 8 x this: PLOC alone.
-                               // zr_host.cpp picks n / 16 within 4096 ... 65536
+                               // zr_host.cpp picks n / 64 within 4096 ... 65536
 };
 
 // where a tree's leaves put their primitive records: the scene's final arrays and the first index this tree may use per leaf kind

@@ -1228,12 +1228,13 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     for (int k = 0; k < 8; k++) bp.leaf_cap[k] = leaf_cap[k];
     bp.open_ratio = (float)env_double("ZR_BVH_OPEN_RATIO", 1.25);
     bp.radius = (int)env_double("ZR_BVH_PLOC_RADIUS", 16);
-    // PLOC stops at n / 16 clusters (4096 ... 65536) and the host's SAH builder arranges those: the larger the SAH-built top, the closer
-    // the walk comes to the host tree's (cfg3 EXTEND per frame: no top +7.8 %, 16384 clusters +2.6 %, 65536 +1.7 % — the whole frame
-    // then equals the host tree's — for 19 / 19 / 28 ms of commit; profiles/r3_builders.txt).  ZR_BVH_TOP overrides (0: PLOC to the root)
+    // PLOC stops at n / 64 clusters (4096 ... 65536) and the host's SAH builder arranges those: the larger the SAH-built top, the closer
+    // the walk comes to the host tree's, and the longer the host's pass takes (cfg3 EXTEND per frame against the host tree's: no top
+    // +8.3 %, 16384 clusters +2.6 %, 65536 +2.3 %, for 17 / 19 / 28 ms of commit — the reference commits once per frame, so the default
+    // is the 16384 a million objects get; profiles/r3_builders.txt).  ZR_BVH_TOP overrides (0: PLOC to the root)
     {
         const double top_env = env_double("ZR_BVH_TOP", -1);
-        bp.top_clusters = top_env >= 0 ? (int)top_env : (int)std::min<size_t>(65536, std::max<size_t>(4096, (size_t)n / 16));
+        bp.top_clusters = top_env >= 0 ? (int)top_env : (int)std::min<size_t>(65536, std::max<size_t>(4096, (size_t)n / 64));
     }
     zr::BuildPrimOut out;
     out.spheres = s->d_spheres.p; out.sphere_mat = s->d_sphere_mat.p; out.tri_v = s->d_tri_v.p; out.tri_s = s->d_tri_s.p;
@@ -1582,7 +1583,7 @@ int zr_scene_commit(zr_scene* s) {
     if (s->media.size() > 65535) return fail(ZR_E_INVALID, "at most 65535 media (RNG key layout, zr_rng.h)");
     {   // which builder.  ZR_BVH_BUILD=device | host forces one; otherwise worlds of at least ZR_BVH_DEVICE_MIN entries (131072: from
         // there on the device build's top is arranged by SAH, zr_build.h) are built on the device: cfg3's 1M triangles commit in
-        // 28 ms instead of 109 and the frame takes the same time on either tree (EXTEND alone 1.7 % more) — profiles/r3_builders.txt;
+        // 19 ms instead of 106 and the frame takes 1 % longer than on the host's tree (EXTEND alone 2.6 %) — profiles/r3_builders.txt;
         // a small world is built faster by the host than a few dozen kernel launches take
         const char* bm = std::getenv("ZR_BVH_BUILD");
         const bool force_dev = bm && std::strcmp(bm, "device") == 0, force_host = bm && std::strcmp(bm, "host") == 0;
@@ -1904,17 +1905,21 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     }
     // A world of a handful of objects is rendered by the FUSED kernel (zr_stream.hip: fused_render): every object tested per
     // segment, the path in registers, no tree, no slot pool.  Testing all objects costs time in proportion to their number, the
-    // pipeline about the same per segment whatever the scene: the switch-over is ZR_FUSED_MAX objects.  Callers that poll
-    // (cancellation, live preview) and the split passes stay on the pipeline, which has round boundaries to poll at.
-    if (mode == 0 && !keep_going && !progress && s->fused_ok && s->leaf_level <= 2 && s->leaf_objects > 0 && (double)s->leaf_objects <= env_double("ZR_FUSED_MAX", ZR_FUSED_OBJECTS) &&
+    // pipeline about the same per segment whatever the scene: the switch-over is ZR_FUSED_MAX objects.  A caller that polls
+    // (cancellation, lines_rendered, live preview) gets the frame in sixteen launches with the poll between them; the split passes
+    // stay on the pipeline.
+    if (mode == 0 && s->fused_ok && s->leaf_level <= 2 && s->leaf_objects > 0 && (double)s->leaf_objects <= env_double("ZR_FUSED_MAX", ZR_FUSED_OBJECTS) &&
         env_double("ZR_FUSED", 1) != 0) {
         if (c->fused_blocks == 0) c->fused_blocks = zr::fused_blocks();
         HostTimer ftimer(c);
+        int parts = 1;
+        if (keep_going || progress) HIP_OK(hipMemsetAsync(c->d_partial.p, 0, samples_n * sizeof(double), stream));   // a cancelled frame / a preview reduces what exists
         hipError_t fe = zr::fused_render_frame(s->ds, dc, de, seed, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p, c->fused_blocks, d_out, c->d_ctr.p, count != 0,
-                                               s->leaf_level <= 1 ? 1 : 2, stream, &ftimer, s->fused);
+                                               s->leaf_level <= 1 ? 1 : 2, stream, &ftimer, s->fused, keep_going, progress, &parts);
         if (fe != hipSuccess) return fail(ZR_E_DEVICE, "fused small-scene kernel failed: %s", hipGetErrorString(fe));
-        c->last_rounds = 1; c->last_path = 3;
+        c->last_rounds = (uint64_t)(parts < 0 ? -parts : parts); c->last_path = 3;
         HIP_OK(hipStreamSynchronize(stream));
+        if (parts < 0) return fail(ZR_E_CANCELLED, "render cancelled after %d of 16 parts", -parts);
         return ZR_OK;
     }
     c->last_path = 2;

@@ -65,7 +65,7 @@ struct FusedObjs {
 int fused_blocks();
 hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
                               unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer,
-                              const FusedObjs& objs);
+                              const FusedObjs& objs, volatile const uint8_t* keep_going = nullptr, StreamProgress* progress = nullptr, int* parts_done = nullptr);
 hipError_t stream_trace(const DScene& sc, const double* d_rays, uint32_t n, uint64_t seed, uint64_t pixel, uint32_t bounce, zr_hit* d_out,
                         void* pool, unsigned int* d_ctl, void* d_overflow, uint32_t ovf_levels, int extend_blocks, unsigned long long* gctr, int leaf_level,
                         hipStream_t stream);

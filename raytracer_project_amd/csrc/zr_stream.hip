@@ -781,6 +781,8 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
 struct FusedBuf {
     const uint32_t* pixels; double* samples; unsigned int* uctl;   // uctl[32 s]: chunk counter of shard s
     uint32_t spp, n_units;
+    uint32_t chunk_lo, chunk_hi;   // this launch hands out the chunks [chunk_lo, chunk_hi) of ST_FUSED_CHUNK units (a frame in one launch, or in
+                                   // parts when the caller polls for cancellation / progress between them)
 };
 // plain medium from a kernel-argument record (medium_plain_t's arithmetic: constant_medium.hpp:39-77 on a bare boundary)
 __device__ __forceinline__ bool medium_rec_t(const double* q, const Ray& r, double tmin, double tmax, const Rng& g, double& t) {
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, D
     bool units_left = true;
     uint32_t cn[4] = {0, 0, 0, 0}, c_samp = 0, c_seg = 0, c_hit = 0;
     unsigned long long c_draws = 0;
-    const unsigned long long n_chunks = ((unsigned long long)B.n_units + ST_FUSED_CHUNK - 1) / ST_FUSED_CHUNK;
+    const unsigned long long n_chunks = B.chunk_hi;
     for (;;) {
         // ---- regeneration: idle lanes take the wave's next units
         const unsigned long long idle = __ballot(!active);
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, D
                 uint32_t nb = 0;
                 if (lane == 0) nb = atomicAdd(&B.uctl[32 * shard], 1u);
                 nb = __builtin_amdgcn_readfirstlane(nb);
-                const unsigned long long c = (unsigned long long)nb * ST_SHARDS + shard;   // chunk index
+                const unsigned long long c = (unsigned long long)B.chunk_lo + (unsigned long long)nb * ST_SHARDS + shard;   // chunk index
                 if (c < n_chunks) {
                     chunk_next = (uint32_t)(c * ST_FUSED_CHUNK);
                     const unsigned long long e = c * ST_FUSED_CHUNK + ST_FUSED_CHUNK;
@@ -1266,23 +1268,49 @@ int fused_blocks() {
 }
 hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,
                               unsigned int* d_ctl, int blocks, double* out, unsigned long long* gctr, bool count, int level, hipStream_t stream, StreamTimer* timer,
-                              const FusedObjs& fo) {
+                              const FusedObjs& fo, volatile const uint8_t* keep_going, StreamProgress* progress, int* parts_done) {
     const uint32_t n_units = n_pix * spp;
     const size_t W = stream_ctl_words();
     hipError_t e;
-    if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
     FusedBuf B; B.pixels = d_pixels; B.samples = d_samples; B.uctl = d_ctl + (size_t)ST_MAX_POOLS * W; B.spp = spp; B.n_units = n_units;
     const unsigned long long n_chunks = ((unsigned long long)n_units + ST_FUSED_CHUNK - 1) / ST_FUSED_CHUNK;
-    unsigned long long want_blocks = (n_chunks + 3) / 4;   // no more waves than chunks
-    const dim3 grid((unsigned)(want_blocks < (unsigned long long)blocks ? (want_blocks ? want_blocks : 1) : blocks)), block(256);
-    if (timer) timer->begin(stream, 1);
-    if (level <= 1) { if (count) hipLaunchKernelGGL((fused_render<1, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<1, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
-    else { if (count) hipLaunchKernelGGL((fused_render<2, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<2, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
-    if (timer) timer->end(stream, 1);
+    // one launch for the whole frame — or, for a caller that polls (render_flag, lines_rendered, the live preview of camera.hpp:548-552 /
+    // main.cpp:1576), sixteen launches over consecutive parts of the unit range with the poll between them (samples[] was zeroed, so the
+    // reduce of a partial frame is the mean of the samples finished so far, as in the pipeline)
+    const int parts = (keep_going || progress) && n_chunks >= 64 ? 16 : 1;
     StreamBuf R = make_buf(nullptr, 0, spp, n_units, n_pix, d_pixels, d_samples, d_ctl, d_ctl, 0, 0);
+    bool cancelled = false;
+    int done = 0;
+    for (int p = 0; p < parts && !cancelled; p++) {
+        B.chunk_lo = (uint32_t)(n_chunks * (unsigned long long)p / (unsigned long long)parts);
+        B.chunk_hi = (uint32_t)(n_chunks * (unsigned long long)(p + 1) / (unsigned long long)parts);
+        if (B.chunk_hi == B.chunk_lo) continue;
+        if ((e = hipMemsetAsync(d_ctl, 0, (ST_MAX_POOLS + 1) * W * sizeof(unsigned int), stream)) != hipSuccess) return e;
+        const unsigned long long want_blocks = ((unsigned long long)(B.chunk_hi - B.chunk_lo) + 3) / 4;   // no more waves than chunks
+        const dim3 grid((unsigned)(want_blocks < (unsigned long long)blocks ? (want_blocks ? want_blocks : 1) : blocks)), block(256);
+        if (timer) timer->begin(stream, 1);
+        if (level <= 1) { if (count) hipLaunchKernelGGL((fused_render<1, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<1, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
+        else { if (count) hipLaunchKernelGGL((fused_render<2, true>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); else hipLaunchKernelGGL((fused_render<2, false>), grid, block, 0, stream, sc, cam, env, seed, B, gctr, fo); }
+        if (timer) timer->end(stream, 1);
+        done = p + 1;
+        if (parts > 1 && p + 1 < parts) {
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if (progress) {
+                bool reduced = false;
+                if (out && progress->wants_frame()) {
+                    hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, R, cam, out);
+                    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+                    reduced = true;
+                }
+                progress->report((double)(p + 1) / parts, reduced);
+            }
+            if (keep_going && *keep_going == 0) cancelled = true;
+        }
+    }
     if (timer) timer->begin(stream, 3);
     if (out) hipLaunchKernelGGL(stream_reduce, dim3((n_pix + 3) / 4), dim3(256), 0, stream, R, cam, out);
     if (timer) timer->end(stream, 3);
+    if (parts_done) *parts_done = cancelled ? -done : done;
     return hipGetLastError();
 }
 
