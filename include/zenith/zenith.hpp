@@ -22,8 +22,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <typeinfo>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -182,17 +185,36 @@ namespace zenith {
 
 constexpr uint32_t no_material = 0xFFFFFFFFu;
 
+// vectors of the large arrays: resize() leaves new elements uninitialised (no 160 MB zero-fill by one thread before the threads of
+// a bulk flatten write them; their pages are first touched by those threads)
+template <class T>
+struct noinit_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = noinit_allocator<U>; };
+    noinit_allocator() = default;
+    template <class U> noinit_allocator(const noinit_allocator<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using nvec = std::vector<T, noinit_allocator<T>>;
+
 struct flat_scene {
-    std::vector<double> spheres, tri_v, tri_n, cubes;
-    std::vector<uint32_t> sphere_mat, tri_mat, cube_mat;
+    std::vector<double> spheres, cubes;
+    nvec<double> tri_v, tri_n;
+    std::vector<uint32_t> sphere_mat, cube_mat;
+    nvec<uint32_t> tri_mat;
     std::vector<zr_medium> media;
     std::vector<zr_xform_op> ops;
-    std::vector<zr_object> objects;
+    nvec<zr_object> objects;
     std::vector<zr_group> groups;
     std::vector<zr_material> materials;
     std::vector<zr_texture> textures;
     std::vector<unsigned char> texels;
     std::vector<std::string> warnings;
+    // empties the scene but keeps the arrays' memory: a camera flattens its world on every render, and a quarter of a gigabyte of
+    // freshly mapped pages costs more to touch than a million triangles cost to copy
+    void clear() {
+        spheres.clear(); cubes.clear(); tri_v.clear(); tri_n.clear(); sphere_mat.clear(); cube_mat.clear(); tri_mat.clear(); media.clear(); ops.clear();
+        objects.clear(); groups.clear(); materials.clear(); textures.clear(); texels.clear(); warnings.clear();
+    }
     zr_scene_desc desc() const {
         zr_scene_desc d{};
         d.spheres = spheres.data(); d.sphere_mat = sphere_mat.data(); d.n_spheres = sphere_mat.size();
@@ -235,11 +257,37 @@ public:
         fs.sphere_mat.push_back(material_id(m));
         emit(ZR_PRIM_SPHERE, (uint32_t)fs.sphere_mat.size() - 1);
     }
+    // (the hot call of a flatten: a million-triangle world comes through here once per render, on the caller's clock)
     void emit_triangle(const point3 v[3], const vec3 n[3], const shared_ptr<material>& m) {
-        for (int k = 0; k < 3; k++) fs.tri_v.insert(fs.tri_v.end(), {v[k].x(), v[k].y(), v[k].z()});
-        for (int k = 0; k < 3; k++) fs.tri_n.insert(fs.tri_n.end(), {n[k].x(), n[k].y(), n[k].z()});
+        const size_t i = fs.tri_mat.size();
+        fs.tri_v.resize(i * 9 + 9); fs.tri_n.resize(i * 9 + 9);
+        double* tv = fs.tri_v.data() + i * 9; double* tn = fs.tri_n.data() + i * 9;
+        for (int k = 0; k < 3; k++) { tv[3 * k] = v[k].x(); tv[3 * k + 1] = v[k].y(); tv[3 * k + 2] = v[k].z(); tn[3 * k] = n[k].x(); tn[3 * k + 1] = n[k].y(); tn[3 * k + 2] = n[k].z(); }
         fs.tri_mat.push_back(material_id(m));
-        emit(ZR_PRIM_TRIANGLE, (uint32_t)fs.tri_mat.size() - 1);
+        emit(ZR_PRIM_TRIANGLE, (uint32_t)i);
+    }
+    // BULK: n bare triangles of one list in one go (hittable_list::flatten on long runs).  Returns false when the builder is in a
+    // state where entries are not plain world entries (capturing a template, inside a medium's boundary): the caller then emits
+    // them one by one.  Otherwise the arrays are grown by n, `first_tri` / `first_obj` say where, and every world entry of the run
+    // shares ONE copy of the open wrapper chain.
+    bool begin_bulk_triangles(size_t n, size_t& first_tri, size_t& first_obj, uint32_t& chain_first, uint32_t& chain_count) {
+        if (!caps.empty() || in_boundary) return false;
+        first_tri = fs.tri_mat.size(); first_obj = fs.objects.size();
+        fs.tri_v.resize((first_tri + n) * 9); fs.tri_n.resize((first_tri + n) * 9); fs.tri_mat.resize(first_tri + n);
+        fs.objects.resize(first_obj + n);
+        chain_count = (uint32_t)chain.size();
+        chain_first = copy_chain(0, chain.size());
+        return true;
+    }
+    void end_bulk_triangles(size_t n_tri, size_t n_obj) {   // the run turned out shorter: cut the arrays back
+        fs.tri_v.resize(n_tri * 9); fs.tri_n.resize(n_tri * 9); fs.tri_mat.resize(n_tri); fs.objects.resize(n_obj);
+    }
+    // a list of n objects is about to be flattened: make room once instead of growing by doubling (mostly triangles in the lists
+    // that are long enough to matter; capacity that stays unused is never touched)
+    void reserve_hint(size_t n) {
+        if (n < 4096) return;
+        fs.tri_v.reserve(fs.tri_v.size() + n * 9); fs.tri_n.reserve(fs.tri_n.size() + n * 9); fs.tri_mat.reserve(fs.tri_mat.size() + n);
+        if (caps.empty()) fs.objects.reserve(fs.objects.size() + n);
     }
     void emit_cube(const vec3& he, const point3& c, const point3& mn, const point3& mx, const shared_ptr<material>& m) {
         fs.cubes.insert(fs.cubes.end(), {he.x(), he.y(), he.z(), c.x(), c.y(), c.z(), mn.x(), mn.y(), mn.z(), mx.x(), mx.y(), mx.z()});
@@ -300,7 +348,7 @@ public:
         std::vector<zr_group> kept;
         for (size_t g = 0; g < fs.groups.size(); g++)
             if (uses[g] > 1 || (uses[g] == 1 && always && *always && *always != '0')) { new_id[g] = (uint32_t)kept.size(); kept.push_back(fs.groups[g]); }
-        std::vector<zr_object> out;
+        nvec<zr_object> out;
         out.reserve(fs.objects.size());
         for (const zr_object& o : fs.objects) {
             if (o.type != ZR_PRIM_GROUP) { out.push_back(o); continue; }
@@ -326,6 +374,7 @@ private:
     std::vector<capture> caps;
     std::unordered_map<const void*, uint32_t> tmpl_ids;   // shared child -> its template
     std::unordered_map<const material*, uint32_t> mat_ids;
+    const material* last_mat_ = nullptr; uint32_t last_mat_id_ = 0;   // the last lookup of material_id()
     std::unordered_map<const texture*, uint32_t> tex_ids;
 public:
     std::unordered_map<uint32_t, shared_ptr<material>> mat_ptrs;   // flattened material id -> the object it came from
@@ -691,11 +740,14 @@ inline uint32_t zenith::scene_builder::texture_id(const shared_ptr<texture>& t) 
 }
 inline uint32_t zenith::scene_builder::material_id(const shared_ptr<material>& m) {
     if (!m) return zenith::no_material;
+    if (m.get() == last_mat_) return last_mat_id_;   // (a mesh's triangles share one material: no hash lookup per triangle)
     auto it = mat_ids.find(m.get());
+    if (it != mat_ids.end()) { last_mat_ = m.get(); last_mat_id_ = it->second; }
     if (it != mat_ids.end()) return it->second;
     uint32_t id = m->flatten(*this);
     mat_ids[m.get()] = id;
     mat_ptrs[id] = m;
+    last_mat_ = m.get(); last_mat_id_ = id;
     return id;
 }
 
@@ -709,7 +761,7 @@ public:
     void add(shared_ptr<hittable> o) { objects.push_back(o); bbox = aabb(bbox, o->bounding_box()); }
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
-    void flatten(zenith::scene_builder& b) const override { for (const auto& o : objects) o->flatten(b); }
+    void flatten(zenith::scene_builder& b) const override;   // (defined after `triangle`: long runs of triangles are flattened by all threads)
 private:
     aabb bbox;
 };
@@ -745,8 +797,62 @@ public:
     void set_material(shared_ptr<material> m) { mat = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_triangle(v, n, mat); }
 private:
+    friend class hittable_list;
     point3 v[3]; vec3 n[3]; shared_ptr<material> mat;
 };
+
+// A world is flattened once per render, on the caller's clock (the reference rebuilds its world on every restart, main.cpp:1492-1500):
+// a million triangles one virtual call at a time took 0.21-0.25 s.  Runs of at least 16384 consecutive `triangle` objects are
+// written by all threads instead (same arrays, same order: entry k of the run is triangle first + k), everything else as before.
+inline void hittable_list::flatten(zenith::scene_builder& b) const {
+    const size_t N = objects.size();
+    b.reserve_hint(N);
+    size_t i = 0;
+    while (i < N) {
+        size_t first_tri = 0, first_obj = 0; uint32_t cf = 0, cc = 0;
+        const size_t n = N - i;
+        const hittable& head = *objects[i];
+        if (n >= 16384 && typeid(head) == typeid(triangle) && b.begin_bulk_triangles(n, first_tri, first_obj, cf, cc)) {
+            // optimistic: room for all n, every thread copies its share and stops at the first object that is not a triangle; the run
+            // ends at the earliest such object and the arrays are cut back to it.  Materials are collected as pointers and turned into
+            // ids afterwards, in order (registering a material flattens its textures: not a job for worker threads).
+            std::vector<const material*> mp(n);
+            const unsigned hw = std::thread::hardware_concurrency();
+            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, hw ? hw : 1u), n / 8192));
+            std::vector<size_t> stop(T, n);
+            auto work = [&](size_t t, size_t a, size_t e) {
+                for (size_t k = a; k < e; k++) {
+                    const hittable& h = *objects[i + k];
+                    if (typeid(h) != typeid(triangle)) { stop[t] = k; return; }
+                    const triangle& tr = static_cast<const triangle&>(h);
+                    double* tv = b.fs.tri_v.data() + (first_tri + k) * 9; double* tn = b.fs.tri_n.data() + (first_tri + k) * 9;
+                    for (int c = 0; c < 3; c++) { tv[3 * c] = tr.v[c].x(); tv[3 * c + 1] = tr.v[c].y(); tv[3 * c + 2] = tr.v[c].z(); tn[3 * c] = tr.n[c].x(); tn[3 * c + 1] = tr.n[c].y(); tn[3 * c + 2] = tr.n[c].z(); }
+                    mp[k] = tr.mat.get();
+                    zr_object o{}; o.type = ZR_PRIM_TRIANGLE; o.index = (uint32_t)(first_tri + k); o.chain_first = cf; o.chain_count = cc;
+                    b.fs.objects[first_obj + k] = o;
+                }
+            };
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; t++) th.emplace_back(work, t, n * t / T, n * (t + 1) / T);
+            work(0, 0, n / T);
+            for (auto& x : th) x.join();
+            size_t run = n;
+            for (size_t t = 0; t < T; t++) if (stop[t] < n) { run = stop[t]; break; }   // (chunks are in order: the first one that stopped ends the run)
+            b.end_bulk_triangles(first_tri + run, first_obj + run);
+            {   // pointers -> ids, in order; the triangle itself is visited again only when its material has not been seen just before
+                const material* last = nullptr; uint32_t last_id = 0; bool have = false;
+                for (size_t k = 0; k < run; k++) {
+                    if (!have || mp[k] != last) { last = mp[k]; last_id = b.material_id(static_cast<const triangle&>(*objects[i + k]).mat); have = true; }
+                    b.fs.tri_mat[first_tri + k] = last_id;
+                }
+            }
+            i += run;
+            continue;
+        }
+        objects[i]->flatten(b);   // (not a long run of triangles, or a builder that is capturing: one by one)
+        i++;
+    }
+}
 
 class cube : public hittable {
 public:
@@ -1133,6 +1239,20 @@ struct context_lease {
     ~context_lease() { if (ctx) contexts().release(ctx); }
     operator zr_ctx*() const { return ctx; }
 };
+// Flattened worlds are leased from a process-wide stash as well: a camera flattens its world on every render, and reusing the
+// arrays of an earlier render saves touching a quarter of a gigabyte of fresh pages for a million triangles.
+struct flat_stash { std::mutex m; std::vector<std::unique_ptr<flat_scene>> free; };
+inline flat_stash& flat_scenes() { static flat_stash s; return s; }
+struct flat_lease {
+    std::unique_ptr<flat_scene> fs;
+    flat_lease() {
+        { std::lock_guard<std::mutex> lk(flat_scenes().m); if (!flat_scenes().free.empty()) { fs = std::move(flat_scenes().free.back()); flat_scenes().free.pop_back(); } }
+        if (!fs) fs.reset(new flat_scene()); else fs->clear();
+    }
+    flat_lease(const flat_lease&) = delete;
+    flat_lease& operator=(const flat_lease&) = delete;
+    ~flat_lease() { std::lock_guard<std::mutex> lk(flat_scenes().m); if (flat_scenes().free.size() < 2) flat_scenes().free.push_back(std::move(fs)); }
+};
 // the device hit() / scatter() calls of scene objects use: the one of the camera that rendered last (camera::device), 0 before that
 inline std::atomic<int>& object_device() { static std::atomic<int> d{0}; return d; }
 
@@ -1279,9 +1399,16 @@ public:
         aspect_ratio = double(image_width) / image_height;
         lines_rendered = 0;
         render_accumulator.assign((size_t)image_width * image_height, color(0, 0, 0));  // the reference only fills (camera.hpp:420)
-        zenith::flat_scene fs; zenith::scene_builder b(fs);
+        const bool stats = std::getenv("ZR_COMMIT_STATS") != nullptr;
+        auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_ph = now_s();
+        auto ph = [&](const char* what) { if (stats) { const double t = now_s(); std::fprintf(stderr, "[zenith] render: %-20s %.1f ms\n", what, (t - t_ph) * 1e3); t_ph = t; } };
+        zenith::flat_lease lease_fs;                 // (the arrays of an earlier render of this process are reused: no fresh pages to touch)
+        zenith::flat_scene& fs = *lease_fs.fs;
+        zenith::scene_builder b(fs);
         world.flatten(b);
         b.finish();
+        ph("flatten");
         zr_env zenv = zenith::to_zr_env(env, b);
         for (const auto& w : fs.warnings) std::cerr << "[zenith] " << w << "\n";
         zenith::object_device() = device;
@@ -1294,6 +1421,7 @@ public:
         zr_scene_desc d = fs.desc();
         rc = sc ? zr_scene_set_all_borrowed(sc, &d) : ZR_E_DEVICE;
         if (rc == ZR_OK) rc = zr_scene_commit(sc);
+        ph("commit");
         if (rc == ZR_OK) {
             zr_camera zc{};
             zc.image_width = image_width; zc.image_height = image_height; zc.samples_per_pixel = samples_per_pixel; zc.max_depth = max_depth;
@@ -1302,6 +1430,7 @@ public:
             rc = zr_render(ctx, sc, &zc, &zenv, seed, nullptr, 0, reinterpret_cast<double*>(render_accumulator.data()),
                            reinterpret_cast<volatile const uint8_t*>(&render_flag), reinterpret_cast<volatile int*>(&lines_rendered));
             zr_get_counters(ctx, &last_counters);
+            ph("zr_render");
             if (rc == ZR_OK && (use_albedo_buffer || use_normal_buffer || use_z_depth_buffer)) {
                 const size_t npx = (size_t)image_width * image_height;
                 if (use_albedo_buffer) albedo_buffer.assign(npx, color(0, 0, 0));

@@ -2115,8 +2115,11 @@ int zr_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_env* 
     if ((rc = c->d_out.alloc(npx * 3))) return rc;
     HIP_OK(hipMemsetAsync(c->d_out.p, 0, npx * 3 * sizeof(double), c->stream));
     if (rows_done) *rows_done = 0;
-    std::vector<double> frame(npx * 3);
+    // a whole frame goes straight into the caller's buffer; a region through a staging copy (only its pixels may be touched)
+    const bool whole = (size_t)plan.tiles.size() == (size_t)plan.tiles_x * plan.tiles_y && plan.x0 == 0 && plan.y0 == 0 && plan.x1 == plan.W && plan.y1 == plan.H;
+    std::vector<double> frame(whole ? 0 : npx * 3);
     auto copy_out = [&]() -> int {   // the region's pixels of the device frame -> the caller's buffer
+        if (whole) { HIP_OK(hipMemcpy(out_rgb, c->d_out.p, npx * 3 * sizeof(double), hipMemcpyDeviceToHost)); return ZR_OK; }
         HIP_OK(hipMemcpy(frame.data(), c->d_out.p, frame.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int32_t t : plan.tiles) {
             int tx = (t % plan.tiles_x) * plan.ts, ty = (t / plan.tiles_x) * plan.ts;
