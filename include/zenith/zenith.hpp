@@ -270,17 +270,23 @@ public:
     // state where entries are not plain world entries (capturing a template, inside a medium's boundary): the caller then emits
     // them one by one.  Otherwise the arrays are grown by n, `first_tri` / `first_obj` say where, and every world entry of the run
     // shares ONE copy of the open wrapper chain.
-    bool begin_bulk_triangles(size_t n, size_t& first_tri, size_t& first_obj, uint32_t& chain_first, uint32_t& chain_count) {
-        if (!caps.empty() || in_boundary) return false;
+    bool begin_bulk_triangles(size_t n, size_t& first_tri, size_t& first_obj, uint32_t& chain_first, uint32_t& chain_count, bool& entries) {
+        if (in_boundary) return false;
+        if (!caps.empty() && chain.size() != caps.back().base) return false;   // inside a template under wrappers of its own: members, one by one
+        entries = caps.empty();   // inside a template the triangles are a run of the template, not world entries
         first_tri = fs.tri_mat.size(); first_obj = fs.objects.size();
         fs.tri_v.resize((first_tri + n) * 9); fs.tri_n.resize((first_tri + n) * 9); fs.tri_mat.resize(first_tri + n);
-        fs.objects.resize(first_obj + n);
-        chain_count = (uint32_t)chain.size();
-        chain_first = copy_chain(0, chain.size());
+        chain_count = 0; chain_first = 0;
+        if (entries) { fs.objects.resize(first_obj + n); chain_count = (uint32_t)chain.size(); chain_first = copy_chain(0, chain.size()); }
         return true;
     }
-    void end_bulk_triangles(size_t n_tri, size_t n_obj) {   // the run turned out shorter: cut the arrays back
-        fs.tri_v.resize(n_tri * 9); fs.tri_n.resize(n_tri * 9); fs.tri_mat.resize(n_tri); fs.objects.resize(n_obj);
+    void end_bulk_triangles(size_t first_tri, size_t run, size_t n_obj, bool entries) {   // the run is `run` long: cut the arrays back; in a template, note it
+        fs.tri_v.resize((first_tri + run) * 9); fs.tri_n.resize((first_tri + run) * 9); fs.tri_mat.resize(first_tri + run);
+        if (entries) { fs.objects.resize(n_obj); return; }
+        tmpl& t = templates[caps.back().tmpl];
+        if (!t.items.empty() && t.items.back().what == 0 && t.items.back().inner.empty() && t.items.back().index + t.items.back().count == first_tri) { t.items.back().count += (uint32_t)run; return; }
+        tmpl_item m; m.what = 0; m.type = ZR_PRIM_TRIANGLE; m.index = (uint32_t)first_tri; m.count = (uint32_t)run;
+        t.items.push_back(std::move(m));
     }
     // a list of n objects is about to be flattened: make room once instead of growing by doubling (mostly triangles in the lists
     // that are long enough to matter; capacity that stays unused is never touched)
@@ -781,6 +787,7 @@ private:
     point3 center; double radius_arg; shared_ptr<material> mat; aabb bbox;
 };
 
+namespace zenith { template <class Get> size_t flatten_triangle_run(scene_builder& b, size_t n, Get&& get); }
 class triangle : public hittable {
 public:
     triangle(const point3& a, const point3& b, const point3& c, const vec3& n0, const vec3& n1, const vec3& n2, shared_ptr<material> m)
@@ -797,59 +804,65 @@ public:
     void set_material(shared_ptr<material> m) { mat = m; zr_device_cache_.reset(); }
     void flatten(zenith::scene_builder& b) const override { b.emit_triangle(v, n, mat); }
 private:
-    friend class hittable_list;
+    template <class Get> friend size_t zenith::flatten_triangle_run(zenith::scene_builder&, size_t, Get&&);
     point3 v[3]; vec3 n[3]; shared_ptr<material> mat;
 };
 
 // A world is flattened once per render, on the caller's clock (the reference rebuilds its world on every restart, main.cpp:1492-1500):
 // a million triangles one virtual call at a time took 0.21-0.25 s.  Runs of at least 16384 consecutive `triangle` objects are
 // written by all threads instead (same arrays, same order: entry k of the run is triangle first + k), everything else as before.
+// a run of triangle objects through the builder's bulk entry: `get(k)` = object k of n.  Returns how many were taken (0: the
+// builder wants them one by one, or the first object is no triangle)
+namespace zenith {
+template <class Get>
+inline size_t flatten_triangle_run(scene_builder& b, size_t n, Get&& get) {
+    size_t first_tri = 0, first_obj = 0; uint32_t cf = 0, cc = 0; bool entries = true;
+    if (n < 16384) return 0;
+    { const hittable& head = get(0); if (typeid(head) != typeid(triangle)) return 0; }
+    if (!b.begin_bulk_triangles(n, first_tri, first_obj, cf, cc, entries)) return 0;
+    // optimistic: room for all n, every thread copies its share and stops at the first object that is not a triangle; the run ends
+    // at the earliest such object and the arrays are cut back to it.  Materials are collected as pointers and turned into ids
+    // afterwards, in order (registering a material flattens its textures: not a job for worker threads).
+    std::vector<const material*> mp(n);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, hw ? hw : 1u), n / 8192));
+    std::vector<size_t> stop(T, n);
+    auto work = [&](size_t t, size_t a, size_t e) {
+        for (size_t k = a; k < e; k++) {
+            const hittable& h = get(k);
+            if (typeid(h) != typeid(triangle)) { stop[t] = k; return; }
+            const triangle& tr = static_cast<const triangle&>(h);
+            double* tv = b.fs.tri_v.data() + (first_tri + k) * 9; double* tn = b.fs.tri_n.data() + (first_tri + k) * 9;
+            for (int c = 0; c < 3; c++) { tv[3 * c] = tr.v[c].x(); tv[3 * c + 1] = tr.v[c].y(); tv[3 * c + 2] = tr.v[c].z(); tn[3 * c] = tr.n[c].x(); tn[3 * c + 1] = tr.n[c].y(); tn[3 * c + 2] = tr.n[c].z(); }
+            mp[k] = tr.mat.get();
+            if (entries) { zr_object o{}; o.type = ZR_PRIM_TRIANGLE; o.index = (uint32_t)(first_tri + k); o.chain_first = cf; o.chain_count = cc; b.fs.objects[first_obj + k] = o; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; t++) th.emplace_back(work, t, n * t / T, n * (t + 1) / T);
+    work(0, 0, n / T);
+    for (auto& x : th) x.join();
+    size_t run = n;
+    for (size_t t = 0; t < T; t++) if (stop[t] < n) { run = stop[t]; break; }   // (chunks are in order: the first one that stopped ends the run)
+    b.end_bulk_triangles(first_tri, run, first_obj + run, entries);
+    {   // pointers -> ids, in order; the triangle itself is visited again only when its material has not been seen just before
+        const material* last = nullptr; uint32_t last_id = 0; bool have = false;
+        for (size_t k = 0; k < run; k++) {
+            if (!have || mp[k] != last) { last = mp[k]; last_id = b.material_id(static_cast<const triangle&>(get(k)).mat); have = true; }
+            b.fs.tri_mat[first_tri + k] = last_id;
+        }
+    }
+    return run;
+}
+}  // namespace zenith
 inline void hittable_list::flatten(zenith::scene_builder& b) const {
     const size_t N = objects.size();
     b.reserve_hint(N);
     size_t i = 0;
     while (i < N) {
-        size_t first_tri = 0, first_obj = 0; uint32_t cf = 0, cc = 0;
-        const size_t n = N - i;
-        const hittable& head = *objects[i];
-        if (n >= 16384 && typeid(head) == typeid(triangle) && b.begin_bulk_triangles(n, first_tri, first_obj, cf, cc)) {
-            // optimistic: room for all n, every thread copies its share and stops at the first object that is not a triangle; the run
-            // ends at the earliest such object and the arrays are cut back to it.  Materials are collected as pointers and turned into
-            // ids afterwards, in order (registering a material flattens its textures: not a job for worker threads).
-            std::vector<const material*> mp(n);
-            const unsigned hw = std::thread::hardware_concurrency();
-            const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(16u, hw ? hw : 1u), n / 8192));
-            std::vector<size_t> stop(T, n);
-            auto work = [&](size_t t, size_t a, size_t e) {
-                for (size_t k = a; k < e; k++) {
-                    const hittable& h = *objects[i + k];
-                    if (typeid(h) != typeid(triangle)) { stop[t] = k; return; }
-                    const triangle& tr = static_cast<const triangle&>(h);
-                    double* tv = b.fs.tri_v.data() + (first_tri + k) * 9; double* tn = b.fs.tri_n.data() + (first_tri + k) * 9;
-                    for (int c = 0; c < 3; c++) { tv[3 * c] = tr.v[c].x(); tv[3 * c + 1] = tr.v[c].y(); tv[3 * c + 2] = tr.v[c].z(); tn[3 * c] = tr.n[c].x(); tn[3 * c + 1] = tr.n[c].y(); tn[3 * c + 2] = tr.n[c].z(); }
-                    mp[k] = tr.mat.get();
-                    zr_object o{}; o.type = ZR_PRIM_TRIANGLE; o.index = (uint32_t)(first_tri + k); o.chain_first = cf; o.chain_count = cc;
-                    b.fs.objects[first_obj + k] = o;
-                }
-            };
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < T; t++) th.emplace_back(work, t, n * t / T, n * (t + 1) / T);
-            work(0, 0, n / T);
-            for (auto& x : th) x.join();
-            size_t run = n;
-            for (size_t t = 0; t < T; t++) if (stop[t] < n) { run = stop[t]; break; }   // (chunks are in order: the first one that stopped ends the run)
-            b.end_bulk_triangles(first_tri + run, first_obj + run);
-            {   // pointers -> ids, in order; the triangle itself is visited again only when its material has not been seen just before
-                const material* last = nullptr; uint32_t last_id = 0; bool have = false;
-                for (size_t k = 0; k < run; k++) {
-                    if (!have || mp[k] != last) { last = mp[k]; last_id = b.material_id(static_cast<const triangle&>(*objects[i + k]).mat); have = true; }
-                    b.fs.tri_mat[first_tri + k] = last_id;
-                }
-            }
-            i += run;
-            continue;
-        }
-        objects[i]->flatten(b);   // (not a long run of triangles, or a builder that is capturing: one by one)
+        const size_t took = zenith::flatten_triangle_run(b, N - i, [&](size_t k) -> const hittable& { return *objects[i + k]; });
+        if (took) { i += took; continue; }
+        objects[i]->flatten(b);   // (not a long run of triangles, or a builder that wants them one by one)
         i++;
     }
 }
@@ -1095,7 +1108,16 @@ public:
     bool hit(const ray& r, interval ray_t, hit_record& rec, int = 0, bool = false) const override { return zenith::device_hit(*this, r, ray_t, rec); }
     aabb bounding_box() const override { return bbox; }
     void set_material(std::shared_ptr<material> m) { mat = m; }   // like the reference's: does not re-material existing triangles
-    void flatten(zenith::scene_builder& b) const override { b.emit_run(this, [&] { for (const auto& t : tris) t->flatten(b); }); }
+    void flatten(zenith::scene_builder& b) const override {
+        b.emit_run(this, [&] {
+            size_t i = 0;
+            while (i < tris.size()) {
+                const size_t took = zenith::flatten_triangle_run(b, tris.size() - i, [&](size_t k) -> const hittable& { return *tris[i + k]; });
+                if (took) { i += took; continue; }
+                tris[i]->flatten(b); i++;
+            }
+        });
+    }
     size_t triangle_count() const { return tris.size(); }
 private:
     std::vector<shared_ptr<triangle>> tris;

@@ -56,12 +56,15 @@ def test_tile_sharding_gloo(exchange, world, tile, built, tmp_path):
     out = tmp_path / "frame.npy"
     env = dict(os.environ, ZR_ROOT=ROOT, ZR_OUT=str(out), OMP_NUM_THREADS="1", ZR_MULTI_EXCHANGE=exchange, ZR_TILE=str(tile))
     import socket
-    with socket.socket() as sk:   # a free port per case: back-to-back launches on one fixed port met its TIME_WAIT now and then
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(2):   # (the port is free when probed and may be taken by the time the launcher binds it: one retry on a fresh port)
+        with socket.socket() as sk:   # a free port per case: back-to-back launches on one fixed port met its TIME_WAIT now and then
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(script)]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if p.returncode == 0:
+            break
     assert p.returncode == 0, p.stdout + p.stderr
     tiles = sorted(int(l.split()[-1]) for l in p.stdout.splitlines() if l.startswith("rank"))
     n_tiles = ((96 + tile - 1) // tile) * ((64 + tile - 1) // tile)   # mix0 is 96 x 64
