@@ -288,8 +288,9 @@ def main():
                                             "them at random_record_rate_G_per_s against ~60 G/s beyond L2 / ~206 G/s L2-resident (scripts/dev/randread.hip)")
         if path == 2 and valu_issue is not None and valu_issue >= 0.7:
             # the counters overrule the guess: the walk's vector instructions (FP32 slab tests, the sort of four children, FP64 primitive tests) fill the issue slots
-            bound, why = "valu-issue", (f"SQ_INSTS_VALU x 4 cycles fill {100 * valu_issue:.0f} % of the chip's vector issue slots over the kernel's active cycles (1024 SIMDs): the walk is limited by "
-                                        f"the instructions it executes at {100 * node_util:.0f} % / {100 * leaf_util:.0f} % lane utilisation of its NODE / LEAF phases, not by memory (L2 hit rate {l2_hit})")
+            bound, why = "valu-issue", (f"SQ_INSTS_VALU x 4 cycles fill {100 * valu_issue:.0f} % of the chip's vector issue slots over the kernel's active cycles (1024 SIMDs): the walk executes them at "
+                                        f"{100 * node_util:.0f} % / {100 * leaf_util:.0f} % lane utilisation of its NODE / LEAF phases (L2 hit rate {l2_hit}).  Measured at the knee: 6.8 % fewer vector instructions left "
+                                        "the duration unchanged, 9 % more cost 10 % (profiles/r3_experiments_ab.txt) - the vector pipe and the walk's fetch path are in balance")
         bound_source = (f"counters: {traffic_file}" if (l2_hit is not None or fp64_frac is not None or valu_issue is not None) else "working set vs L2 (no counter pass of this kernel source committed)")
         out = {
             "metric": "Msamples/sec (rays·bounces)", "value": round(value, 3), "unit": "Msamples/s",

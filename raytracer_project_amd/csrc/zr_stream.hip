@@ -149,16 +149,18 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
 
 // ---- EXTEND: closest hit for every active slot ------------------------------------------------------------
 // Walks the 4-wide tree (zr_device_types.h: FP32 root in the kernel arguments, 64-byte nodes with boxes on an 8-bit
-// grid below it).  The kernel is bound by VALU issue and node fetches together (rocprofv3: SQ_INSTS_VALU x 4 clocks /
-// 1024 SIMDs ~ its duration; 128-byte FP32 nodes with fewer operations per visit were 15 % slower), so the slab test
-// is arranged for the fewest operations, and it is CONSERVATIVE: a superset of box hits cannot change the closest
+// grid below it).  The kernel sits where VALU issue and the node / primitive fetches are in balance (rocprofv3:
+// SQ_INSTS_VALU x 4 clocks / 1024 SIMDs ~ its duration — and yet 6.8 % fewer vector instructions per launch, round 3's
+// node step, left the duration where it was, while 4 / 9 / 17 % MORE cost 2 / 10 / 15 %: profiles/r3_experiments_ab.txt;
+// 128-byte FP32 nodes with fewer operations per visit were 15 % slower), so the slab test is arranged for few operations
+// AND few bytes, and it is CONSERVATIVE: a superset of box hits cannot change the closest
 // primitive, and every primitive test stays FP64.
 //   per ray:   id = 1 / (float)d (float, taken as exact: it perturbs t by a relative 2^-23),  c = (float)(-o * id)
 //   per plane: t = fmaf(P, id, c)                          (root: P is an FP32 plane)
 //              t = fmaf(q, a, b), a = scale * id (exact, scale is a power of two), b = fmaf(origin, id, c)
 //   error:     |t - (P - o) id| <= 2^-24 (|t| + |b| + |c|), and |b| <= |t| + 255 |a|
-// The absolute part of that bound is folded, per axis, into the constants: the plane a ray meets first on an axis
-// (the lower one when id > 0) uses c_n = c - 2^-22 |c|, the other one c_f = c + 2^-22 |c| (and b_n, b_f move by a
+// The absolute part of that bound is folded, per axis, into the constants: the plane a ray ENTERS an axis' slab through
+// (the lower one when id > 0) uses c_n = c - 2^-22 |c|, the one it leaves through c_f = c + 2^-22 |c| (and b_n, b_f move by a
 // further 2^-15 |a|); a slack shared by the three axes would let an axis with a tiny d inflate the other two.  The
 // relative part lowers the entry distance and raises the exit distance by |t| 2^-20.  An axis whose 1/d or o/d
 // leaves the float range gets id = 0, c = NaN: its planes evaluate to NaN, which fminf/fmaxf ignore, i.e. the slab
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
     uint32_t slot = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     float idx_ = 0, idy_ = 0, idz_ = 0;
-    float clx = 0, cly = 0, clz = 0, chx = 0, chy = 0, chz = 0;  // per axis: c for the LOWER plane and for the UPPER plane (slack folded in)
+    float cnx = 0, cny = 0, cnz = 0, cfx = 0, cfy = 0, cfz = 0;  // per axis: c for the plane the ray ENTERS through and for the one it LEAVES through (slack folded in)
     double tbest = INF;
     float tbest_f = INFf;
     uint32_t kbest = NONE, ibest = 0;
@@ -272,13 +274,15 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
         if (!(fabsf(idx_) < 1.2676506e30f) || !(fabsf(ocx) < 1.3292280e36f)) { idx_ = 0.0f; ocx = NANf; }    \
         if (!(fabsf(idy_) < 1.2676506e30f) || !(fabsf(ocy) < 1.3292280e36f)) { idy_ = 0.0f; ocy = NANf; }    \
         if (!(fabsf(idz_) < 1.2676506e30f) || !(fabsf(ocz) < 1.3292280e36f)) { idz_ = 0.0f; ocz = NANf; }    \
-        /* the lower plane is the entry plane when id > 0: it gets the smaller constant */                   \
-        const float sx = copysignf(fabsf(ocx) * 2.3841858e-7f, idx_), sy = copysignf(fabsf(ocy) * 2.3841858e-7f, idy_), sz = copysignf(fabsf(ocz) * 2.3841858e-7f, idz_); \
-        clx = ocx - sx; chx = ocx + sx; cly = ocy - sy; chy = ocy + sy; clz = ocz - sz; chz = ocz + sz;      \
+        /* the ENTRY plane of an axis (the lower one when id > 0) gets the smaller constant, the exit plane the larger one */ \
+        const float sx = fabsf(ocx) * 2.3841858e-7f, sy = fabsf(ocy) * 2.3841858e-7f, sz = fabsf(ocz) * 2.3841858e-7f; \
+        cnx = ocx - sx; cfx = ocx + sx; cny = ocy - sy; cfy = ocy + sy; cnz = ocz - sz; cfz = ocz + sz;      \
     }
+// the root's FP32 planes (once per ray): lower / upper plane with the constant of the role it plays for this ray
 #define ZR_FBOX(N, C, TN, RF)                                                                               \
-    ZR_SLAB(fmaf((N).lox[C], idx_, clx), fmaf((N).hix[C], idx_, chx), fmaf((N).loy[C], idy_, cly), fmaf((N).hiy[C], idy_, chy), \
-            fmaf((N).loz[C], idz_, clz), fmaf((N).hiz[C], idz_, chz), (N).ref[C], TN, RF)
+    ZR_SLAB(fmaf((N).lox[C], idx_, idx_ > 0.0f ? cnx : cfx), fmaf((N).hix[C], idx_, idx_ > 0.0f ? cfx : cnx),  \
+            fmaf((N).loy[C], idy_, idy_ > 0.0f ? cny : cfy), fmaf((N).hiy[C], idy_, idy_ > 0.0f ? cfy : cny),  \
+            fmaf((N).loz[C], idz_, idz_ > 0.0f ? cnz : cfz), fmaf((N).hiz[C], idz_, idz_ > 0.0f ? cfz : cnz), (N).ref[C], TN, RF)
 // the four children by entry distance (5-comparator network): push far -> near, continue with the nearest
 #define ZR_DESCEND()                                                                                        \
     {                                                                                                       \
@@ -378,14 +382,27 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
             if (st == X_NODE) {
                 float tn0, tn1, tn2, tn3;
                 uint32_t r0, r1, r2, r3;
+#ifdef ST_DUMMY_VALU   /* measurement aid: ST_DUMMY_VALU extra vector instructions per node step (four independent chains) */
+                {
+                    float d0_ = idx_, d1_ = idy_, d2_ = idz_, d3_ = cnx;
+#pragma unroll
+                    for (int k_ = 0; k_ < ST_DUMMY_VALU / 4; k_++) {
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d0_)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d1_));
+                        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d2_)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d3_));
+                    }
+                    asm volatile("" ::"v"(d0_), "v"(d1_), "v"(d2_), "v"(d3_));
+                }
+#endif
+#ifdef ST_NODE_MINMAX   /* A/B: the min / max form of round 2 */
                 const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
                 const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
+                const bool px_ = idx_ > 0.0f, py_ = idy_ > 0.0f, pz_ = idz_ > 0.0f;
                 // t = fmaf(q, a, b): a = scale * id, b = the node origin's parametric distance (the lower planes' b moved
                 // by -2^-15 a, the upper planes' by +2^-15 a: towards "earlier" resp. "later" whatever the sign of id)
                 const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
-                const float blx = fmaf(ax_, -3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, clx)), bhx = fmaf(ax_, 3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, chx));
-                const float bly = fmaf(ay_, -3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, cly)), bhy = fmaf(ay_, 3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, chy));
-                const float blz = fmaf(az_, -3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, clz)), bhz = fmaf(az_, 3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, chz));
+                const float blx = fmaf(ax_, -3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, (px_ ? cnx : cfx))), bhx = fmaf(ax_, 3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, (px_ ? cfx : cnx)));
+                const float bly = fmaf(ay_, -3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, (py_ ? cny : cfy))), bhy = fmaf(ay_, 3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, (py_ ? cfy : cny)));
+                const float blz = fmaf(az_, -3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, (pz_ ? cnz : cfz))), bhz = fmaf(az_, 3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, (pz_ ? cfz : cnz)));
 #define ZR_QBOX(C, RF_IN, TN, RF)                                                                                          \
     ZR_SLAB(fmaf((float)((w1.z >> (8 * C)) & 0xFFu), ax_, blx), fmaf((float)((w2.y >> (8 * C)) & 0xFFu), ax_, bhx),         \
             fmaf((float)((w1.w >> (8 * C)) & 0xFFu), ay_, bly), fmaf((float)((w2.z >> (8 * C)) & 0xFFu), ay_, bhy),         \
@@ -395,6 +412,47 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                 ZR_QBOX(2, ref.z, tn2, r2)
                 ZR_QBOX(3, ref.w, tn3, r3)
 #undef ZR_QBOX
+#else
+                const uint4* nq = reinterpret_cast<const uint4*>(sc.quads + cur);
+                const uint4 w0 = nq[0], w1 = nq[1], w2 = nq[2], ref = nq[3];
+                // t = fmaf(q, a, b): a = scale * id, b = the node origin's parametric distance (the entry planes' b moved by -2^-15 |a|,
+                // the exit planes' by +2^-15 |a|).  The sign of id says which of an axis' two planes the ray enters through — for all four
+                // children at once: the word of lower planes or the word of upper planes — so no per-child min / max is needed, and the
+                // children are evaluated two at a time (v_pk_fma_f32): the planes' values are those of the min / max form, bit for bit.
+                typedef float f2_ __attribute__((ext_vector_type(2)));
+                const float ax_ = __uint_as_float(w0.w) * idx_, ay_ = __uint_as_float(w1.x) * idy_, az_ = __uint_as_float(w1.y) * idz_;
+                const float bnx = fmaf(fabsf(ax_), -3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, cnx)), bfx = fmaf(fabsf(ax_), 3.0517578e-5f, fmaf(__uint_as_float(w0.x), idx_, cfx));
+                const float bny = fmaf(fabsf(ay_), -3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, cny)), bfy = fmaf(fabsf(ay_), 3.0517578e-5f, fmaf(__uint_as_float(w0.y), idy_, cfy));
+                const float bnz = fmaf(fabsf(az_), -3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, cnz)), bfz = fmaf(fabsf(az_), 3.0517578e-5f, fmaf(__uint_as_float(w0.z), idz_, cfz));
+                const bool px_ = idx_ > 0.0f, py_ = idy_ > 0.0f, pz_ = idz_ > 0.0f;
+                const uint32_t qnx = px_ ? w1.z : w2.y, qfx = px_ ? w2.y : w1.z;
+                const uint32_t qny = py_ ? w1.w : w2.z, qfy = py_ ? w2.z : w1.w;
+                const uint32_t qnz = pz_ ? w2.x : w2.w, qfz = pz_ ? w2.w : w2.x;
+#define ZR_Q2(W, S) ((f2_){(float)(((W) >> (S)) & 0xFFu), (float)(((W) >> ((S) + 8)) & 0xFFu)})
+#define ZR_T2(W, S, A, Bc) __builtin_elementwise_fma(ZR_Q2(W, S), ((f2_){(A), (A)}), ((f2_){(Bc), (Bc)}))
+                const f2_ nx01 = ZR_T2(qnx, 0, ax_, bnx), nx23 = ZR_T2(qnx, 16, ax_, bnx), fx01 = ZR_T2(qfx, 0, ax_, bfx), fx23 = ZR_T2(qfx, 16, ax_, bfx);
+                const f2_ ny01 = ZR_T2(qny, 0, ay_, bny), ny23 = ZR_T2(qny, 16, ay_, bny), fy01 = ZR_T2(qfy, 0, ay_, bfy), fy23 = ZR_T2(qfy, 16, ay_, bfy);
+                const f2_ nz01 = ZR_T2(qnz, 0, az_, bnz), nz23 = ZR_T2(qnz, 16, az_, bnz), fz01 = ZR_T2(qfz, 0, az_, bfz), fz23 = ZR_T2(qfz, 16, az_, bfz);
+#undef ZR_T2
+#undef ZR_Q2
+#define ZR_QBOX(NX, NY, NZ, FX, FY, FZ, RF_IN, TN, RF)                                                      \
+    {                                                                                                       \
+        float n_ = fmaxf(fmaxf(NX, NY), fmaxf(NZ, 0.000999f));                                              \
+        float f_ = fminf(fminf(FX, FY), fminf(FZ, tbest_f));                                                \
+        n_ = fmaf(fabsf(n_), -9.5367432e-7f, n_);                                                           \
+        f_ = fmaf(fabsf(f_), 9.5367432e-7f, f_);                                                            \
+        const bool empty_ = (RF_IN) == ZR_REF_EMPTY;                                                        \
+        const bool hit_ = (n_ <= f_) && !empty_;                                                            \
+        if (COUNT && !empty_) c_nodes++;                                                                    \
+        TN = hit_ ? n_ : INFf;                                                                              \
+        RF = (RF_IN);                                                                                       \
+    }
+                ZR_QBOX(nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x, ref.x, tn0, r0)
+                ZR_QBOX(nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y, ref.y, tn1, r1)
+                ZR_QBOX(nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x, ref.z, tn2, r2)
+                ZR_QBOX(nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y, ref.w, tn3, r3)
+#undef ZR_QBOX
+#endif
                 ZR_DESCEND()
             }
         } else {
