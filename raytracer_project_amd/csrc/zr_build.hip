@@ -990,9 +990,9 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     NodePair* pairs = (NodePair*)alloc_keep((size_t)n * sizeof(NodePair));
     if (!quads || !pairs) { err_ = "out of device memory for the tree's records"; return hipErrorOutOfMemory; }
     hipLaunchKernelGGL(k_fill_u32, grid_for(N), dim3(256), 0, st_, qroot, N, NONE);
-    PlanOut h_po; std::memset(&h_po, 0, sizeof h_po);
-    h_po.counter = root_in_array ? 1u : 0u;
-    if ((e = hipMemcpyAsync(po, &h_po, sizeof h_po, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
+    PlanOut h_po_in; std::memset(&h_po_in, 0, sizeof h_po_in);   // (source of an asynchronous copy: not written again before the next synchronisation)
+    h_po_in.counter = root_in_array ? 1u : 0u;
+    if ((e = hipMemcpyAsync(po, &h_po_in, sizeof h_po_in, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(qinst, 0, (size_t)n * 4, st_)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(qdem, 0, (size_t)n * 4, st_)) != hipSuccess) return e;
     if (root_in_array) {   // the root is quad 0, level 0
@@ -1040,6 +1040,7 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     hipLaunchKernelGGL(k_emit, grid_for(n), dim3(256), 0, st_, in, d_objects, d_code, first_triangle, n, dfs_obj, dfs_kind, rank, out, compound, state + 20);
     uint32_t n_compound = 0;
     BNode h_root;
+    PlanOut h_po;
     if ((e = hipMemcpyAsync(&h_po, po, sizeof h_po, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&n_compound, state + 20, 4, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&h_root, bn + root, sizeof h_root, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;

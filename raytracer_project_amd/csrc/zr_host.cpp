@@ -1148,6 +1148,12 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     const uint32_t n = (uint32_t)objs.size();
     hipStream_t st = s->ctx->stream;
     int rc;
+    // every group's tree is a build of its own (a few dozen launches and a handful of synchronisations, ~1 ms however small the run):
+    // a world of very many small groups is the host builder's, which builds them on its threads
+    if ((double)s->groups.size() > env_double("ZR_BVH_DEVICE_MAX_GROUPS", 256)) {
+        std::fprintf(stderr, "[zr] device BVH build: %zu groups of triangles: host builder\n", s->groups.size());
+        return ZR_FALLBACK_HOST;
+    }
     // 1. classification + array sizes
     std::vector<uint8_t> code(n);
     const bool bake = env_double("ZR_BAKE_TRIANGLES", 1) != 0;
@@ -1189,7 +1195,8 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     DevBuf<double> r_sph, r_tri_v, r_tri_n, r_cubes, r_gbox;
     DevBuf<uint32_t> r_sph_mat, r_tri_mat, r_cube_mat, d_inst_group, d_run_demand, d_run_root, d_run_qroot;
     DevBuf<zr_medium> r_media; DevBuf<zr_object> r_objs; DevBuf<uint8_t> r_code;
-    struct Pinned { std::vector<void*> p; ~Pinned() { for (void* q : p) (void)hipHostUnregister(q); } } pinned;
+    // (an early return leaves copies in flight: they are waited for before their source pages are unpinned)
+    struct Pinned { hipStream_t st; std::vector<void*> p; ~Pinned() { if (!p.empty()) (void)hipStreamSynchronize(st); for (void* q : p) (void)hipHostUnregister(q); } } pinned{st, {}};
     auto send = [&](auto& buf, const auto* src, size_t count) -> int {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(src)>>;
         int r = buf.alloc(count);
