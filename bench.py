@@ -131,8 +131,10 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    p = subprocess.run(cmd, env=env)
-    raise SystemExit(p.returncode)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:   # rank 0's JSON line goes to stdout; whatever else the ranks or their libraries print (gloo's connection notes) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+    raise SystemExit(p.wait())
 
 
 def main():
