@@ -329,7 +329,7 @@ def main():
                          "kernel_ms_per_step": round(sum(launches) / max(1, args.steps), 3),
                          "algorithmic_bytes_per_launch": int(bytes_local / launches_per_step),
                          "model": ("32 B per child box tested + 72 B per triangle + 32 B per sphere + 48 B per cube test (SURVEY 8(d) prices a cube at 96 B; this layout stores 6 of "
-                                   "its 12 doubles — a placed cube's record is 96 B — so the figure is conservative); the 76 B per hit of shading data belong to SHADE "
+                                   "its 12 doubles — a placed cube's record is 128 B — so the figure is conservative); the 76 B per hit of shading data belong to SHADE "
                                    "and are NOT in this kernel's figure")},
         }
         if world == 1 and not args.no_cpu_baseline:

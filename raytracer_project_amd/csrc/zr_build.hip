@@ -720,17 +720,18 @@ __global__ __launch_bounds__(256) void k_emit(BuildSceneIn in, const zr_object* 
         double* d = out.spheres + di * 4;
         d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = r;
         out.sphere_mat[di] = force_front ? (mat | 0x80000000u) : mat;
-    } else if (bk == 4) {   // put_pcube: cube -> [rotate_y] -> translate in one record
+    } else if (bk == 4) {   // put_pcube: cube -> [scale] -> [rotate_y] -> translate in one record
         const double* q = in.cubes + (size_t)o.index * 12;
-        double rec[12] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0};
+        double rec[ZR_PCUBE_STRIDE] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0, 1, 1, 1, 0};
         uint32_t mat = in.cube_mat[o.index];
         for (int k = (int)o.chain_count - 1; k >= 0; k--) {
             const zr_xform_op op = in.ops[o.chain_first + k];
             if (op.kind == ZR_OP_TRANSLATE) { rec[6] = op.a[0]; rec[7] = op.a[1]; rec[8] = op.a[2]; }
             else if (op.kind == ZR_OP_ROTATE_Y) { rec[9] = op.a[0]; rec[10] = op.a[1]; rec[11] = 1.0; }
+            else if (op.kind == ZR_OP_SCALE) { rec[12] = op.a[0]; rec[13] = op.a[1]; rec[14] = op.a[2]; rec[15] = 1.0; }
             else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
         }
-        for (int k = 0; k < 12; k++) out.pcubes[di * 12 + k] = rec[k];
+        for (int k = 0; k < ZR_PCUBE_STRIDE; k++) out.pcubes[di * ZR_PCUBE_STRIDE + k] = rec[k];
         out.pcube_mat[di] = mat;
     } else {
         const bool mat_only = bk == 2;   // material-only chain: the outermost wrapper is applied last

@@ -213,8 +213,11 @@ __device__ __forceinline__ bool cube_t(const double* q, const Ray& r, double tmi
     return true;
 }
 
-// A placed cube: the ray goes through translate::hit's and rotate_y::hit's first halves (translate.hpp:15-22, rotate_y.hpp:44-56)
-// exactly as chain_ray would apply them, then cube::hit — the wrapper parameters come with the record instead of from an op list
+// A placed cube: the ray goes through translate::hit's, rotate_y::hit's and scale::hit's first halves (translate.hpp:15-22, rotate_y.hpp:44-56,
+// scale.hpp:20-24) exactly as chain_ray would apply them, then cube::hit — the wrapper parameters come with the record instead of from an op list
+// SCALED = false: the caller knows that no record carries a scale (the fused small-scene kernel: the host sends worlds with scaled placed cubes
+// through the pipeline instead), and the division code is not compiled into it
+template <bool SCALED = true>
 __device__ __forceinline__ Ray pcube_ray(const double* q, Ray r) {
     r.o = r.o - mk(q[6], q[7], q[8]);
     if (q[11] != 0.0) {
@@ -223,10 +226,15 @@ __device__ __forceinline__ Ray pcube_ray(const double* q, Ray r) {
         const double dx = c * r.d.x + s * r.d.z, dz = -s * r.d.x + c * r.d.z;
         r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
     }
+    if (SCALED && q[15] != 0.0) {   // scale::hit's first half (scale.hpp:20-24), the arithmetic of apply_op_ray
+        r.o = mk(r.o.x / q[12], r.o.y / q[13], r.o.z / q[14]);
+        r.d = mk(r.d.x / q[12], r.d.y / q[13], r.d.z / q[14]);
+    }
     return r;
 }
+template <bool SCALED = true>
 __device__ __forceinline__ bool pcube_t(const double* q, const Ray& r, double tmin, double tmax, double& t) {
-    const Ray lr = pcube_ray(q, r);
+    const Ray lr = pcube_ray<SCALED>(q, r);
     return cube_t(q, lr, tmin, tmax, t);
 }
 
@@ -294,7 +302,7 @@ __device__ inline bool object_t(const DScene& sc, uint32_t kind, uint32_t idx, c
         if (w.type == ZR_PRIM_MEDIUM) return medium_t(sc, w.index, lr, tmin, tmax, g, t);
         return bare_t(sc, w.type, w.index, lr, tmin, tmax, t);
     }
-    if (kind == ZR_KIND_PCUBE) return pcube_t(sc.pcubes + (size_t)idx * 12, r, tmin, tmax, t);
+    if (kind == ZR_KIND_PCUBE) return pcube_t(sc.pcubes + (size_t)idx * ZR_PCUBE_STRIDE, r, tmin, tmax, t);
     if (kind == ZR_PRIM_MEDIUM) return medium_t(sc, idx, r, tmin, tmax, g, t);
     return bare_t(sc, kind, idx, r, tmin, tmax, t);
 }
@@ -484,12 +492,14 @@ __device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, c
 
 // hit record of leaf object (kind, idx) hit by world ray r at distance t
 // `full`: compute every field (known-answer entry); otherwise u/v/tangent only when the material reads them
+template <bool PSCALE = true>
 __device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full = false) {
-    if (kind == ZR_KIND_PCUBE) {   // cube::hit's record in object space, then the second halves of rotate_y::hit and translate::hit, inside-out
-        const double* q = sc.pcubes + (size_t)idx * 12;
-        const Ray lr = pcube_ray(q, r);
+    if (kind == ZR_KIND_PCUBE) {   // cube::hit's record in object space, then the second halves of scale::hit, rotate_y::hit and translate::hit, inside-out
+        const double* q = sc.pcubes + (size_t)idx * ZR_PCUBE_STRIDE;
+        const Ray lr = pcube_ray<PSCALE>(q, r);
         cube_rec_q(q, sc.pcube_mat[idx], lr, t, rec);
         zr_xform_op op; op.mat = 0;
+        if (PSCALE && q[15] != 0.0) { op.kind = ZR_OP_SCALE; op.a[0] = q[12]; op.a[1] = q[13]; op.a[2] = q[14]; apply_op_rec(op, r.d, rec); }   // scale.hpp:29-33 (reads no ray)
         if (q[11] != 0.0) { op.kind = ZR_OP_ROTATE_Y; op.a[0] = q[9]; op.a[1] = q[10]; op.a[2] = 0; apply_op_rec(op, r.d, rec); }   // the ray rotate_y received: translated only, same direction
         op.kind = ZR_OP_TRANSLATE; op.a[0] = q[6]; op.a[1] = q[7]; op.a[2] = q[8];
         apply_op_rec(op, r.d, rec);

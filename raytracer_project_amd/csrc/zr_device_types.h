@@ -38,6 +38,7 @@ static_assert(sizeof(NodePair) == 64, "NodePair must be 64 bytes");
 // lane and instruction, and a random record costs the fabric one request whatever its size.
 //   q[0..2] = lower x, y, z planes, q[3..5] = upper; byte c of each word belongs to child c.
 //   ref[c]: ZR_REF_EMPTY, an inner node's index, or ZR_REF_LEAF | kind << 28 | (count - 1) << 24 | first primitive.
+#define ZR_PCUBE_STRIDE 16 /* doubles per placed-cube record (128 bytes) */
 #define ZR_REF_LEAF 0x80000000u
 #define ZR_REF_EMPTY 0xFFFFFFFFu
 struct alignas(64) NodeQ {
@@ -71,7 +72,7 @@ struct DScene {
                                 // [19] low word bit 0 = front_face forced true (triangle baked from under a translate / rotate_y)
     const double* cubes;        // 6 per cube: half extents, centre
     const uint32_t* cube_mat;
-    const double* pcubes;       // placed cubes, 12 per cube: half extents, centre | translate offset | rotate_y sin, cos, has_rotation | (pad)
+    const double* pcubes;       // placed cubes, ZR_PCUBE_STRIDE (16) per cube: half extents, centre | translate offset | rotate_y sin, cos, has_rotation | scale x, y, z, has_scale
     const uint32_t* pcube_mat;
     const DMedium* media;
     const DWrapped* wrapped;

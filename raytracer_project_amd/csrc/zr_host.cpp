@@ -285,13 +285,15 @@ inline void classify_object(const zr_scene& s, const zr_object& o, bool bake, ui
         }
         if (ok && moved && mat < 0x7FFFFFFFu) { baked = 3; kind = ZR_PRIM_SPHERE; }
     }
-    if (o.type == ZR_PRIM_CUBE) {   // see Flattener::put_pcube: [translate] or [translate, rotate_y], outermost first
-        int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen
+    if (o.type == ZR_PRIM_CUBE) {   // see Flattener::put_pcube: [translate], [translate, rotate_y], each optionally followed by a scale — outermost first
+        int pat = 0; bool ok = true;   // 0 nothing yet, 1 translate seen, 2 translate then rotate_y seen, 3 ... then a scale (the innermost wrapper)
         for (uint32_t q = 0; q < o.chain_count && ok; q++) {
-            const uint32_t kd = s.ops[o.chain_first + q].kind;
+            const zr_xform_op& op = s.ops[o.chain_first + q];
+            const uint32_t kd = op.kind;
             if (kd == ZR_OP_MATERIAL) continue;
             if (kd == ZR_OP_TRANSLATE && pat == 0) pat = 1;
             else if (kd == ZR_OP_ROTATE_Y && pat == 1) pat = 2;
+            else if (kd == ZR_OP_SCALE && (pat == 1 || pat == 2) && op.a[0] != 0.0 && op.a[1] != 0.0 && op.a[2] != 0.0) pat = 3;
             else ok = false;
         }
         if (ok && pat >= 1) { baked = 4; kind = ZR_KIND_PCUBE; }
@@ -519,22 +521,24 @@ struct Flattener {
         d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; d[3] = r;
         sphere_mat[di] = force_front ? (mat | 0x80000000u) : mat;
     }
-    // A cube under translate, or under rotate_y then translate (material_instance wrappers anywhere) — how every cube of the
-    // reference's scenes is placed (scene_management.hpp:132-139, cfg5's walls and boxes) — is stored as a PLACED CUBE: the cube's
-    // own numbers plus the two wrappers' parameters in one record.  The device applies the wrappers' ray and hit-record maps in the
+    // A cube under translate, or under rotate_y then translate, either with a scale as the innermost wrapper (material_instance wrappers
+    // anywhere) — how every cube of the reference's scenes is placed (scene_management.hpp:132-139 and the scaled, turned instances of its
+    // master cube, :178-201; cfg5's walls and boxes) — is stored as a PLACED CUBE: the cube's own numbers plus the wrappers' parameters in one
+    // 128-byte record.  The device applies the wrappers' ray and hit-record maps in the
     // chain's order with the chain's arithmetic (zr_device.h pcube_ray / object_rec), so results are those of the wrapped object;
     // what is saved is the op-list loop, its loads and the registers of the generic chain code in the traversal kernel.
     void put_pcube(size_t di, const zr_object& o) {
         const double* q = &s.cubes[(size_t)o.index * 12];
-        double rec[12] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0};
+        double rec[ZR_PCUBE_STRIDE] = {q[0], q[1], q[2], q[3], q[4], q[5], 0, 0, 0, 0, 1, 0, 1, 1, 1, 0};
         uint32_t mat = s.cube_mat[o.index];
         for (int k = (int)o.chain_count - 1; k >= 0; k--) {   // inside-out: the outermost material_instance is applied last
             const zr_xform_op& op = s.ops[o.chain_first + k];
             if (op.kind == ZR_OP_TRANSLATE) { rec[6] = op.a[0]; rec[7] = op.a[1]; rec[8] = op.a[2]; }
             else if (op.kind == ZR_OP_ROTATE_Y) { rec[9] = op.a[0]; rec[10] = op.a[1]; rec[11] = 1.0; }
+            else if (op.kind == ZR_OP_SCALE) { rec[12] = op.a[0]; rec[13] = op.a[1]; rec[14] = op.a[2]; rec[15] = 1.0; }
             else if (op.kind == ZR_OP_MATERIAL) mat = op.mat;
         }
-        std::memcpy(&pcubes[di * 12], rec, sizeof rec);
+        std::memcpy(&pcubes[di * ZR_PCUBE_STRIDE], rec, sizeof rec);
         pcube_mat[di] = mat;
     }
     // object `oi` as a leaf primitive of a plain kind (sphere / triangle / cube / placed cube) at index di of that kind's array
@@ -935,7 +939,7 @@ struct Flattener {
         spheres.allocate((n_sph + x_sph) * 4); sphere_mat.allocate(n_sph + x_sph);
         tri_v.allocate((n_tri + x_tri) * ZR_TRI_STRIDE); tri_s.allocate((n_tri + x_tri) * 20);
         cubes.allocate((n_cube + x_cube) * 6); cube_mat.allocate(n_cube + x_cube);
-        pcubes.allocate(n_pcube * 12); pcube_mat.allocate(n_pcube);
+        pcubes.allocate(n_pcube * ZR_PCUBE_STRIDE); pcube_mat.allocate(n_pcube);
         media.allocate(n_media + x_media); wrapped.allocate(n_wrapped);
         // 3. leaf primitives of the plain kinds: all threads
         parallel_for(leaves.size(), 2048, [&](size_t a, size_t b) {
@@ -1096,7 +1100,7 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
             return ZR_OK;
         };
         if ((rc = take(ZR_PRIM_SPHERE, s->d_spheres.p, 4, 4)) || (rc = take(ZR_PRIM_TRIANGLE, s->d_tri_v.p, ZR_TRI_STRIDE, 9)) ||
-            (rc = take(ZR_PRIM_CUBE, s->d_cubes.p, 6, 6)) || (rc = take(ZR_KIND_PCUBE, s->d_pcubes.p, 12, 12))) return rc;
+            (rc = take(ZR_PRIM_CUBE, s->d_cubes.p, 6, 6)) || (rc = take(ZR_KIND_PCUBE, s->d_pcubes.p, ZR_PCUBE_STRIDE, ZR_PCUBE_STRIDE))) return rc;
         std::vector<zr::DMedium> hm(cs.leaf_cnt[ZR_PRIM_MEDIUM]);
         if (!hm.empty()) HIP_OK(hipMemcpy(hm.data(), s->d_media.p, hm.size() * sizeof(zr::DMedium), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < hm.size(); i++) {
@@ -1109,7 +1113,9 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
             std::memcpy(&fo.rec[fo.n][7], &idb, 8); std::memcpy(&fo.rec[fo.n][8], &tb, 8);
             fo.n++;
         }
-        s->fused = fo; s->fused_ok = true;
+        bool scaled = false;   // the fused kernel's placed-cube code carries no scale (zr_device.h pcube_ray<false>): such a world takes the pipeline
+        for (uint32_t i = 0; i < fo.n; i++) if (fo.kind[i] == ZR_KIND_PCUBE && fo.rec[i][15] != 0.0) scaled = true;
+        s->fused = fo; s->fused_ok = !scaled;
     }
     {   // which build of the EXTEND kernel this world needs (zr_stream.hip)
         if (cs.n_insts) s->leaf_level = 3;   // placed runs of triangles: the build with the nested walk
@@ -1122,7 +1128,7 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
     s->stack_demand = cs.stack_demand;
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", cs.quad_depth, s->stack_demand);
     s->stats[0] = cs.n_pairs; s->stats[1] = (uint64_t)cs.max_depth; s->stats[2] = n_objs;
-    s->stats[3] = cs.n_pairs * sizeof(zr::NodePair) + cs.n_quads * sizeof(zr::NodeQ) + (cs.n_sph * 4 + cs.n_tri * (ZR_TRI_STRIDE + 20) + cs.n_cube * 6 + cs.n_pcube * 12) * 8 +
+    s->stats[3] = cs.n_pairs * sizeof(zr::NodePair) + cs.n_quads * sizeof(zr::NodeQ) + (cs.n_sph * 4 + cs.n_tri * (ZR_TRI_STRIDE + 20) + cs.n_cube * 6 + cs.n_pcube * ZR_PCUBE_STRIDE) * 8 +
                   (cs.n_sph + cs.n_cube) * 4 + s->texels.size();
     s->builder = cs.builder;
     s->committed = true;
@@ -1217,7 +1223,7 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
         (rc = send(r_cubes, s->cubes.data(), s->cubes.size())) || (rc = send(r_cube_mat, s->cube_mat.data(), s->cube_mat.size())) ||
         (rc = send(r_media, s->media.data(), s->media.size())) || (rc = s->d_ops.upload(s->ops.data(), s->ops.size())) || (rc = send(r_code, code.data(), code.size()))) return rc;
     if ((rc = s->d_spheres.alloc(n_sph * 4)) || (rc = s->d_sphere_mat.alloc(n_sph)) || (rc = s->d_tri_v.alloc(n_tri * ZR_TRI_STRIDE)) || (rc = s->d_tri_s.alloc(n_tri * 20)) ||
-        (rc = s->d_cubes.alloc(n_cube * 6)) || (rc = s->d_cube_mat.alloc(n_cube)) || (rc = s->d_pcubes.alloc(n_pcube * 12)) || (rc = s->d_pcube_mat.alloc(n_pcube)) ||
+        (rc = s->d_cubes.alloc(n_cube * 6)) || (rc = s->d_cube_mat.alloc(n_cube)) || (rc = s->d_pcubes.alloc(n_pcube * ZR_PCUBE_STRIDE)) || (rc = s->d_pcube_mat.alloc(n_pcube)) ||
         (rc = s->d_insts.alloc(n_insts)) || (rc = d_inst_group.alloc(n_insts))) return rc;
     phase("upload as given");
     zr::BuildSceneIn in;

@@ -60,7 +60,7 @@ struct FusedObjs {
     uint32_t n, pad_;
     uint32_t kind[ZR_FUSED_OBJECTS];    // leaf kind (ZR_PRIM_* / ZR_KIND_PCUBE); media here are plain ones only
     uint32_t index[ZR_FUSED_OBJECTS];   // index in that kind's array (what a hit reports)
-    double rec[ZR_FUSED_OBJECTS][12];
+    double rec[ZR_FUSED_OBJECTS][16];   // (a placed cube's record is the longest: ZR_PCUBE_STRIDE)
 };
 int fused_blocks();
 hipError_t fused_render_frame(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, uint32_t spp, uint32_t n_pix, const uint32_t* d_pixels, double* d_samples,

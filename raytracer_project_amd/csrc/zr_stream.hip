@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
                     ZR_POP_NEXT()
                 } else {
                 if (LEVEL == 1) {   // cubes, placed cubes, plain media: no op-list interpreter in this build
-                    if (lkind == ZR_KIND_PCUBE) h = pcube_t(sc.pcubes + (size_t)prim * 12, ray, 0.001, tbest, t);
+                    if (lkind == ZR_KIND_PCUBE) h = pcube_t(sc.pcubes + (size_t)prim * ZR_PCUBE_STRIDE, ray, 0.001, tbest, t);
                     else if (lkind == ZR_PRIM_CUBE) h = cube_t(sc.cubes + (size_t)prim * 6, ray, 0.001, tbest, t);
                     else h = medium_plain_t(sc, prim, ray, 0.001, tbest, g, t);
                 } else h = object_t(sc, lkind, prim, ray, 0.001, tbest, g, t);
@@ -879,7 +879,7 @@ __device__ __forceinline__ void brute_hit(const DScene& sc, const FusedObjs& fo,
         if (k == ZR_PRIM_SPHERE) h = sphere_t(q, ray, 0.001, tbest, t);
         else if (k == ZR_PRIM_TRIANGLE) h = triangle_t(q, ray, 0.001, tbest, t);
         else if (k == ZR_PRIM_CUBE) h = cube_t(q, ray, 0.001, tbest, t);
-        else if (k == ZR_KIND_PCUBE) h = pcube_t(q, ray, 0.001, tbest, t);
+        else if (k == ZR_KIND_PCUBE) h = pcube_t<false>(q, ray, 0.001, tbest, t);   // (no scaled placed cube reaches this kernel: zr_host.cpp finish_commit)
         else h = medium_rec_t(q, ray, 0.001, tbest, g, t);
         if (h) { tbest = t; kbest = k; ibest = fo.index[i]; }
         if (COUNT) { if (k == ZR_PRIM_SPHERE) cn[0]++; else if (k == ZR_PRIM_TRIANGLE) cn[1]++; else if (k == ZR_PRIM_CUBE || k == ZR_KIND_PCUBE) cn[2]++; else cn[3]++; }
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256, ST_FUSED_WAVES) void fused_render(DScene sc, D
                 ended = true;
             } else {
                 Rec rec;
-                object_rec(sc, kind, idx, ray, t_hit, rec);
+                object_rec<false>(sc, kind, idx, ray, t_hit, rec);
                 const V3 em = emitted(sc, rec);
                 V3 att; Ray nr;
                 const bool sc_ok = scatter(sc, ray, rec, att, nr, g);
