@@ -116,6 +116,12 @@ def _random_scene(capi, rng, n_obj):
             for _q in range(int(rng.integers(0, 3))):
                 kind = int(rng.choice([1, 2, 3, 5]))
                 ang = float(rng.uniform(-3, 3)); ops.append(capi.XformOp(kind, int(rng.choice(opaque)), (C.c_double * 3)(math.sin(ang), math.cos(ang), 0.0)))
+            if rng.random() < 0.4:
+                # a scale as the innermost wrapper, the way the reference sizes the instances of its master cube (scene_management.hpp:178-201):
+                # translate [-> rotate_y] -> scale is stored as a placed cube, any other chain goes through the op-list interpreter.  At most
+                # 1.2: a scaled, turned cube must stay inside its lattice cell (see above)
+                sc3 = rng.uniform(0.5, 1.2, 3) if rng.random() < 0.6 else np.full(3, float(rng.uniform(0.5, 1.2)))
+                ops.append(capi.XformOp(4, 0, (C.c_double * 3)(*sc3)))
             objs.append(capi.Object(2, len(cmat) - 1, cf, len(ops) - cf))
     # a medium in a sphere boundary, sometimes wrapped
     spheres += list(rng.uniform(-1, 1, 3)) + [float(rng.uniform(1.0, 2.5))]; smat.append(0)
