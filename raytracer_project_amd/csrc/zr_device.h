@@ -741,6 +741,97 @@ __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec,
     }
 }
 
+// ---- the LEAN shading set: worlds of bare triangles and spheres whose materials are lambertian / metal / dielectric / light with solid-colour textures and
+// no bump map (cfg2, cfg3: DScene::shade_lean, decided at commit).  The same arithmetic as the general routines above with everything such a world cannot
+// reach left out — u, v, tangent, bitangent, image and checker textures, bump maps, wrapper chains — so that SHADE's lean build needs fewer registers:
+// the kernel's speed follows its occupancy (profiles/r4_experiments_ab.txt).
+struct RecL { V3 p, n; uint32_t mat; bool front; };
+// x^5 for Schlick's weight (material.hpp:237-241 calls pow(1 - cosine, 5)): three multiplications, within 2 ulp of pow's result; the value only meets a
+// comparison with a random number, so a different last bit changes a decision with probability ~1e-16 per dielectric hit — and libm's pow costs the
+// lean build its register budget
+__device__ __forceinline__ double pow5(double x) { const double x2 = x * x; return x2 * x2 * x; }
+__device__ __forceinline__ void lean_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, RecL& rec) {
+    rec.p = at(r, t);
+    V3 outward;
+    bool force_front = false;
+    if (kind == ZR_PRIM_SPHERE) {   // sphere.hpp:42-46
+        const double* s = sc.spheres + (size_t)idx * 4;
+        outward = vdiv(rec.p - mk(s[0], s[1], s[2]), s[3]);
+        rec.mat = sc.sphere_mat[idx];
+        if (rec.mat != 0xFFFFFFFFu && (rec.mat & 0x80000000u)) { rec.mat &= 0x7FFFFFFFu; force_front = true; }
+    } else {                        // triangle.hpp:40-79
+        const double* v = sc.tri_s + (size_t)idx * 20;
+        const double* nn = v + 9;
+        V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+        V3 normal = cross(v1 - v0, v2 - v0);
+        V3 C0 = cross(v1 - v0, rec.p - v0);
+        V3 C2 = cross(v0 - v2, rec.p - v2);
+        double area2 = dot(normal, normal);
+        double u = dot(normal, C2) / area2;
+        double w_ = dot(normal, C0) / area2;
+        double w0 = 1.0 - u - w_;
+        outward = unit(w0 * ld3(nn) + u * ld3(nn + 3) + w_ * ld3(nn + 6));
+        rec.mat = (uint32_t)__double_as_longlong(v[18]);
+        force_front = ((uint32_t)__double_as_longlong(v[19]) & 1u) != 0;
+    }
+    rec.front = dot(r.d, outward) < 0;   // hittable.hpp:22-25
+    rec.n = rec.front ? outward : -outward;
+    if (force_front) rec.front = true;
+}
+__device__ __forceinline__ V3 lean_color(const DScene& sc, uint32_t tex) { const zr_texture& t = sc.texs[tex]; return mk(t.color[0], t.color[1], t.color[2]); }
+// emitted + scatter of the hit's material in one look at it
+__device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, const RecL& rec, V3& em, V3& att, Ray& out, Rng& g) {
+    em = mk(0, 0, 0);
+    if (rec.mat >= sc.n_mats) return false;
+    const zr_material& m = sc.mats[rec.mat];
+    const uint32_t kind = m.kind;
+    if (kind == ZR_MAT_LIGHT) { em = lean_color(sc, m.tex); return false; }
+    if (kind == ZR_MAT_LAMBERTIAN) {  // material.hpp:74-96
+        V3 dir = rec.n + random_unit_vector(g);
+        if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = rec.n;
+        out.o = rec.p + (rec.n * 0.0001);
+        out.d = dir;
+        att = lean_color(sc, m.tex);
+        return true;
+    }
+    if (kind == ZR_MAT_METAL) {  // material.hpp:129-151
+        V3 v = unit(rin.d);
+        V3 refl = reflect(v, rec.n);
+        V3 dir = unit(refl + (m.param * random_unit_vector(g)));
+        out.o = rec.p + (0.0001 * rec.n);
+        out.d = dir;
+        att = lean_color(sc, m.tex);
+        return dot(dir, rec.n) > 0;
+    }
+    if (kind == ZR_MAT_DIELECTRIC) {  // material.hpp:192-224, 237-241
+        att = mk(m.tint[0], m.tint[1], m.tint[2]);
+        double ri = rec.front ? (1.0 / m.param) : m.param;
+        V3 ud = unit(rin.d);
+        double ct = fmin(dot(-ud, rec.n), 1.0);
+        double st = sqrt(1.0 - ct * ct);
+        bool refl = ri * st > 1.0;
+        if (!refl) {
+            double r0 = (1 - ri) / (1 + ri);
+            r0 = r0 * r0;
+            double rf = r0 + (1 - r0) * pow5(1 - ct);
+            refl = rf > g.next();
+        }
+        V3 dir;
+        if (refl) dir = reflect(ud, rec.n);
+        else {  // refract, vec3.hpp:209-214
+            double c2 = fmin(dot(-ud, rec.n), 1.0);
+            V3 perp = ri * (ud + c2 * rec.n);
+            V3 par = (-sqrt(fabs(1.0 - len2(perp)))) * rec.n;
+            dir = perp + par;
+        }
+        V3 off = (dot(dir, rec.n) > 0) ? (0.0001 * rec.n) : (-0.0001 * rec.n);
+        out.o = rec.p + off;
+        out.d = dir;
+        return true;
+    }
+    return false;
+}
+
 // ---- background (camera.hpp:828-925) -------------------------------------------------------------------
 __device__ inline V3 background(const DScene& sc, const DEnv& env, V3 rd) {
     if (env.mode == ZR_ENV_SOLID_COLOR) return mk(env.solid[0], env.solid[1], env.solid[2]);

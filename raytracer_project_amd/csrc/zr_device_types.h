@@ -83,6 +83,7 @@ struct DScene {
     const unsigned char* texels;
     uint32_t n_mats;
     uint32_t mat_kinds;  // bit k set: a material of kind k exists (SHADE sorts by kind only when more than one does)
+    uint32_t shade_lean; // 1: SHADE may run its lean build (bare triangles / spheres, lambertian / metal / dielectric / light over solid colours, no bump maps)
     uint32_t leaf_cnt[8]; // leaf objects per kind (the first leaf_cnt[k] records of kind k's array): the fused small-scene kernel tests them all
     NodeF root;          // variant 2: the root of the 4-wide tree
 };

@@ -1124,6 +1124,15 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
         else s->leaf_level = 0;
         const int force = (int)env_double("ZR_EXTEND_LEVEL", -1);
         if (force > s->leaf_level && force <= 3) s->leaf_level = force;
+        // SHADE's lean build (zr_device.h: lean_rec / lean_shade): a world of bare triangles and spheres whose materials are lambertian / metal / dielectric / light
+        // over solid-colour textures, no bump maps — nothing in it reads u, v, a tangent, an image or a wrapper chain
+        bool lean = s->leaf_level == 0 && env_double("ZR_SHADE_LEAN", 1) != 0;
+        for (const zr_material& m : s->materials) {
+            if (m.kind != ZR_MAT_LAMBERTIAN && m.kind != ZR_MAT_METAL && m.kind != ZR_MAT_DIELECTRIC && m.kind != ZR_MAT_LIGHT) lean = false;
+            if (m.bump_tex != ZR_NO_TEXTURE) lean = false;
+            if (m.kind != ZR_MAT_DIELECTRIC && (m.tex >= s->textures.size() || s->textures[m.tex].kind != ZR_TEX_SOLID)) lean = false;
+        }
+        d.shade_lean = lean ? 1u : 0u;
     }
     s->stack_demand = cs.stack_demand;
     if (std::getenv("ZR_QUANT_STATS")) std::fprintf(stderr, "[zr] 4-wide tree: depth %d, worst-case traversal stack %u entries\n", cs.quad_depth, s->stack_demand);

@@ -99,6 +99,29 @@ struct StreamBuf {
     __device__ __forceinline__ void st3(int f, uint32_t slot, V3 v) const { st(f, slot, v.x); st(f + 1, slot, v.y); st(f + 2, slot, v.z); }
 };
 
+// A slot addressed RELATIVE TO ITS 256-SLOT BLOCK (round 4).  SHADE and INIT work on the slots of one block per workgroup, so `base` is the same in every
+// thread (a scalar register pair), `off` a 32-bit byte offset below 48 KB and the field a constant: every row access becomes
+// `global_load/store v, v_off, s[base] offset:imm` with ONE vector register of address for all 23 rows.  Through StreamBuf::cell() every row had a 64-bit
+// address of its own, and the rows a segment reads and writes back kept theirs alive across the whole kernel (12+ registers, part of them spilled in the
+// lean build): SHADE's speed follows its occupancy (profiles/r4_experiments_ab.txt), so registers are time.
+struct SlotAt {
+    const char* base; uint32_t off;
+    __device__ __forceinline__ const char* at(int f) const { return base + (off + (uint32_t)f * 512u); }
+    __device__ __forceinline__ double ld(int f) const { return *reinterpret_cast<const double*>(at(f)); }
+    __device__ __forceinline__ void st(int f, double v) const { *reinterpret_cast<double*>(const_cast<char*>(at(f))) = v; }
+    __device__ __forceinline__ uint2 ld2(int f) const { return *reinterpret_cast<const uint2*>(at(f)); }
+    __device__ __forceinline__ void st2(int f, uint2 v) const { *reinterpret_cast<uint2*>(const_cast<char*>(at(f))) = v; }
+    __device__ __forceinline__ V3 ld3(int f) const { return mk(ld(f), ld(f + 1), ld(f + 2)); }
+    __device__ __forceinline__ void st3(int f, V3 v) const { st(f, v.x); st(f + 1, v.y); st(f + 2, v.z); }
+};
+// slot `block * 256 + src` (src < 256); `block` must be wave-uniform
+__device__ __forceinline__ SlotAt slot_at(const StreamBuf& B, uint32_t block, uint32_t src) {
+    SlotAt a;
+    a.base = reinterpret_cast<const char*>(B.pool) + (size_t)block * (size_t)(4 * SF_N * 512);
+    a.off = (src >> 6) * (uint32_t)(SF_N * 512) + (src & 63u) * 8u;
+    return a;
+}
+
 
 // Which unit is the k-th of shard `shard`.
 //  striped (G = 0): unit_base + k * ST_SHARDS + shard — every shard sweeps the whole frame, one unit in ST_SHARDS.
@@ -122,17 +145,17 @@ __host__ __device__ inline unsigned long long st_first_unit(uint32_t G, uint32_t
 }
 
 // ---- begin a sample in a slot: camera ray + fresh path state --------------------------------------------
-__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, uint32_t slot, uint32_t unit, uint32_t& c_samp) {
+__device__ inline void begin_sample(const StreamBuf& B, const DCamera& cam, uint64_t seed, const SlotAt& S, uint32_t unit, uint32_t& c_samp) {
     const uint32_t pix_i = unit / B.spp, sample = unit - pix_i * B.spp;
     const uint32_t pk = B.pixels[pix_i];
     const int px = (int)(pk & 0xFFFFu), py = (int)(pk >> 16);
     Rng g; g.key = zr_stream_key(seed, (uint64_t)py * (uint64_t)cam.W + (uint64_t)px, (uint64_t)sample); g.k = 0; g.bounce = 0;
     Ray r = camera_ray(cam, px, py, g);
-    B.st3(SF_RAY, slot, r.o); B.st3(SF_RAY + 3, slot, r.d);
-    B.st(SF_KEY, slot, __longlong_as_double((long long)g.key));
+    S.st3(SF_RAY, r.o); S.st3(SF_RAY + 3, r.d);
+    S.st(SF_KEY, __longlong_as_double((long long)g.key));
     uint2 ma; ma.x = (uint32_t)g.k; ma.y = F_FIRST | F_ACTIVE;
     uint2 mb; mb.x = unit; mb.y = 0;
-    B.st2(SF_MA, slot, ma); B.st2(SF_MB, slot, mb);
+    S.st2(SF_MA, ma); S.st2(SF_MB, mb);
     c_samp++;
 }
 
@@ -142,8 +165,9 @@ __global__ __launch_bounds__(256) void stream_init(StreamBuf B, DCamera cam, uin
     if (slot >= B.P) return;
     uint32_t c_samp = 0;
     const unsigned long long u0 = st_first_unit(B.unit_chunk, B.unit0 + slot);
-    if (u0 < (unsigned long long)B.n_units) begin_sample(B, cam, seed, slot, (uint32_t)u0, c_samp);
-    else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
+    const SlotAt S = slot_at(B, blockIdx.x, threadIdx.x);
+    if (u0 < (unsigned long long)B.n_units) begin_sample(B, cam, seed, S, (uint32_t)u0, c_samp);
+    else { uint2 z; z.x = 0; z.y = 0; S.st2(SF_MA, z); }
     if (COUNT && c_samp) atomicAdd(&gctr[0], (unsigned long long)c_samp);
 }
 
@@ -565,8 +589,11 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
 // ray is traced again, at its first hit the sample's stream is positioned after the beauty path (so the SECOND scatter of that
 // hit gets the draws the reference gives it), the scattered path runs as ray_color(scattered, max_depth - 1), and its
 // luma-clamped radiance times the attenuation is written with its class.
-template <bool COUNT, int MODE>
-__global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
+#ifndef ST_SHADE_WAVES_LEAN
+#define ST_SHADE_WAVES_LEAN 6
+#endif
+template <bool COUNT, int MODE, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? ST_SHADE_WAVES_LEAN : ST_SHADE_WAVES) void stream_shade(DScene sc, DCamera cam, DEnv env, uint64_t seed, StreamBuf B,
                                                     unsigned long long* __restrict__ gctr) {
     const uint32_t slot0 = blockIdx.x * 256 + threadIdx.x;
     if (slot0 < ST_SHARDS) B.ctl[16 + 32 * slot0 + 8] = 0;  // EXTEND of the next round starts from chunk 0 of every shard
@@ -587,14 +614,14 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
     __shared__ unsigned int wave_cls[4][8];
     __shared__ uint4 x_mk[256];          // (meta.x, meta.y, hit kind, hit index) of the slot a thread will shade
     __shared__ unsigned char x_src[256]; // ... and which slot of the block that is
-    uint32_t slot;
+    uint32_t src;   // which slot of the block this thread shades
     uint2 m, ki;
     {
         uint2 m0; m0.x = 0; m0.y = 0;
         uint2 k0; k0.x = 0xFFFFFFFFu; k0.y = 0;
-        if (slot0 < B.P) { m0 = B.ld2(SF_MA, slot0); k0 = B.ld2(SF_HIT_KI, slot0); }
+        if (slot0 < B.P) { const SlotAt S0 = slot_at(B, blockIdx.x, threadIdx.x); m0 = S0.ld2(SF_MA); k0 = S0.ld2(SF_HIT_KI); }
 #ifdef ZR_SHADE_NO_PARTITION
-        slot = slot0; m = m0; ki = k0;
+        src = threadIdx.x; m = m0; ki = k0;
 #else
         uint32_t cls = 7;
         if (m0.y & F_ACTIVE) {
@@ -629,10 +656,11 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
         x_src[base + my_rank] = (unsigned char)threadIdx.x;
         __syncthreads();
         mk4 = x_mk[threadIdx.x];
-        slot = blockIdx.x * 256 + x_src[threadIdx.x];
+        src = x_src[threadIdx.x];
         m.x = mk4.x; m.y = mk4.y; ki.x = mk4.z; ki.y = mk4.w;
 #endif
     }
+    const SlotAt S = slot_at(B, blockIdx.x, src);
     bool active_after = false, want_unit = false;
     uint32_t c_samp = 0, c_seg2 = 0, c_hit2 = 0; unsigned long long c_draws = 0;
     {
@@ -655,19 +683,19 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
 #endif
             // every row this segment reads, requested in one go (a row of a slot is always addressable; what a path does not
             // need is not requested: beta before the second hit, the unit id is 8 bytes)
-            Ray ray; ray.o = B.ld3(SF_RAY, slot); ray.d = B.ld3(SF_RAY + 3, slot);
-            Rng g; g.key = (uint64_t)__double_as_longlong(B.ld(SF_KEY, slot)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
-            const uint2 mb_now = B.ld2(SF_MB, slot);
-            const double t_hit = B.ld(SF_HIT_T, slot);
+            Ray ray; ray.o = S.ld3(SF_RAY); ray.d = S.ld3(SF_RAY + 3);
+            Rng g; g.key = (uint64_t)__double_as_longlong(S.ld(SF_KEY)); g.k = m.x; g.bounce = (m.y & 0xFFu) + 1u;  // this query is complete
+            const uint2 mb_now = S.ld2(SF_MB);
+            const double t_hit = S.ld(SF_HIT_T);
             // after the first hit L = 0 and beta = 1 (camera.hpp:930): both stay implicit (two flag bits) until something else is
             // stored, which saves their 48 bytes written and read back per path; the values used are the same (0 + x, 1 * x)
             V3 beta_now = mk(1, 1, 1);
-            if (!first && !(m.y & F_BONE)) beta_now = B.ld3(SF_BETA, slot);
+            if (!first && !(m.y & F_BONE)) beta_now = S.ld3(SF_BETA);
             V3 att0_now = mk(0, 0, 0);
-            if (!first && ki.x == NONE) att0_now = B.ld3(SF_ATT0, slot);   // a miss ends the path: its sample is att0 * (L + beta * background)
+            if (!first && ki.x == NONE) att0_now = S.ld3(SF_ATT0);   // a miss ends the path: its sample is att0 * (L + beta * background)
             int b_inner = (int)((m.y >> 8) & 0xFFu);
             const int depth_inner = cam.max_depth - 1;
-            auto load_L = [&]() { return (m.y & F_LZERO) ? mk(0, 0, 0) : B.ld3(SF_L, slot); };
+            auto load_L = [&]() { return (m.y & F_LZERO) ? mk(0, 0, 0) : S.ld3(SF_L); };
             auto load_beta = [&]() { return beta_now; };
             uint32_t keep_lzero = m.y & F_LZERO;
             // the split passes count segments and hits here (SHADE sees every segment exactly once), so that their EXTEND can be
@@ -697,7 +725,11 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 const double t = t_hit;
                 V3 em, att; Ray nr; bool sc_ok;
                 uint32_t cls_now = 0;
-                {
+                if (LEAN) {
+                    RecL rec;
+                    lean_rec(sc, ki.x, ki.y, ray, t, rec);
+                    sc_ok = lean_shade(sc, ray, rec, em, att, nr, g);
+                } else {
                     Rec rec;
 #ifdef ZR_SHADE_TOUCH
                     asm volatile("" ::"v"(touch), "v"(ray.o.x), "v"(ray.d.z));   // the ray is here, so the touches (older) have returned
@@ -720,8 +752,8 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     if (MODE != 2 && has_em) { add_now = em; has_add = true; }
                     if (!sc_ok || depth_inner <= 0) { ended = true; if (MODE == 2) no_output = true; }
                     else {
-                        B.st3(SF_ATT0, slot, att);   // L = 0, beta = 1: implicit (F_LZERO | F_BONE below)
-                        if (MODE == 2) { uint2 mb = mb_now; mb.y = cls_now; B.st2(SF_MB, slot, mb); }
+                        S.st3(SF_ATT0, att);   // L = 0, beta = 1: implicit (F_LZERO | F_BONE below)
+                        if (MODE == 2) { uint2 mb = mb_now; mb.y = cls_now; S.st2(SF_MB, mb); }
                         b_inner = 0;
                     }
                 } else {      // body of ray_color's loop, camera.hpp:944-983
@@ -745,20 +777,20 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                     if (stop) {
                         if (!have_L) L = load_L();
                         if (MODE == 2) { const double luma = 0.2126 * len(L); if (luma > 2.0) L = L * (2.0 / luma); }
-                        contrib = B.ld3(SF_ATT0, slot) * L; ended = true;
+                        contrib = S.ld3(SF_ATT0) * L; ended = true;
                     } else {
-                        if (have_L) { B.st3(SF_L, slot, L); keep_lzero = 0; }
-                        B.st3(SF_BETA, slot, beta);
+                        if (have_L) { S.st3(SF_L, L); keep_lzero = 0; }
+                        S.st3(SF_BETA, beta);
                     }
                 }
                 if (!ended) {
                     // the path continues: publish the scattered ray (a primary hit's emission waits in SF_SUM)
-                    B.st3(SF_RAY, slot, nr.o); B.st3(SF_RAY + 3, slot, nr.d);
-                    if (has_add) B.st3(SF_SUM, slot, add_now);
+                    S.st3(SF_RAY, nr.o); S.st3(SF_RAY + 3, nr.d);
+                    if (has_add) S.st3(SF_SUM, add_now);
                     m.x = (uint32_t)g.k;
                     m.y = (g.bounce & 0xFFu) | ((uint32_t)b_inner << 8) | F_ACTIVE | (first ? (has_add ? F_L0 : 0u) : (m.y & F_L0)) |
                           (first ? (F_LZERO | F_BONE) : keep_lzero);
-                    B.st2(SF_MA, slot, m);
+                    S.st2(SF_MA, m);
                     active_after = true;
                 }
             }
@@ -766,7 +798,7 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
                 // radiance of this sample = L0 + att0 * L (camera.hpp:1000), written exactly once
                 V3 rad = contrib;
                 if (has_add) rad = add_now + rad;
-                else if (MODE != 2 && !first && (m.y & F_L0)) rad = B.ld3(SF_SUM, slot) + rad;
+                else if (MODE != 2 && !first && (m.y & F_L0)) rad = S.ld3(SF_SUM) + rad;
                 const uint2 mb = mb_now;
                 const uint32_t unit = mb.x;
                 if (MODE != 2 || !no_output) {
@@ -795,8 +827,8 @@ __global__ __launch_bounds__(256, ST_SHADE_WAVES) void stream_shade(DScene sc, D
             if (want_unit) {
                 const unsigned long long k = (unsigned long long)k0 + (unsigned long long)__popcll(wm & ((1ull << wl) - 1ull));
                 const unsigned long long u = st_unit_of(B.unit_chunk, B.unit_base, shard, (unsigned long long)B.shard_k0 + k);
-                if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, slot, (uint32_t)u, c_samp); active_after = true; }
-                else { uint2 z; z.x = 0; z.y = 0; B.st2(SF_MA, slot, z); }
+                if (u < (unsigned long long)B.n_units) { begin_sample(B, cam, seed, S, (uint32_t)u, c_samp); active_after = true; }
+                else { uint2 z; z.x = 0; z.y = 0; S.st2(SF_MA, z); }
             }
         }
     }
@@ -1225,9 +1257,22 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
         if (count) launch_extend<true>(sc, B, o, ovf_levels, eb, gctr, generic, st); else launch_extend<false>(sc, B, o, ovf_levels, eb, gctr, generic, st);
         if (timer) timer->end(st, 1);
     };
+    // development aid: ZR_SHADE_LDS_PAD bytes of dynamic LDS per SHADE block lower the blocks a CU can hold (160 KB: 4 fit by registers; > 40 KB: 3, > 53 KB: 2)
+    static const unsigned shade_pad = std::getenv("ZR_SHADE_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ZR_SHADE_LDS_PAD")) : 0u;
     auto shade = [&](const StreamBuf& B, hipStream_t st) {
         if (timer) timer->begin(st, 2);
         const dim3 sg((B.P + 255) / 256), sb(256);
+        if (sc.shade_lean && mode == 0) {   // the lean build: same arithmetic, fewer registers, 6 waves per SIMD instead of 4 (see lean_rec, zr_device.h)
+            if (count) hipLaunchKernelGGL((stream_shade<true, 0, true>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
+            else hipLaunchKernelGGL((stream_shade<false, 0, true>), sg, sb, shade_pad, st, sc, cam, env, seed, B, gctr);
+            if (timer) timer->end(st, 2);
+            return;
+        }
+        if (shade_pad && mode == 0 && !count) {
+            hipLaunchKernelGGL((stream_shade<false, 0>), sg, sb, shade_pad, st, sc, cam, env, seed, B, gctr);
+            if (timer) timer->end(st, 2);
+            return;
+        }
         if (mode == 1) hipLaunchKernelGGL((stream_shade<true, 1>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);        // the split passes always count
         else if (mode == 2) hipLaunchKernelGGL((stream_shade<true, 2>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
         else if (count) hipLaunchKernelGGL((stream_shade<true, 0>), sg, sb, 0, st, sc, cam, env, seed, B, gctr);
