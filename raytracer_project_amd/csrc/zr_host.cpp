@@ -1429,9 +1429,11 @@ zr_ctx* zr_create(int device_ordinal) {
         c->st_blocks = zr::stream_extend_blocks();
         int over = (int)env_double("ZR_ST_BLOCKS", 0);
         if (over > 0) c->st_blocks = over;
-        // 64 Mi slots = 12.9 GB of path state (of 288 GB): cfg3 368 ms against 392 with 32 Mi and 424 with 16 Mi — a launch that carries
-        // twice the rays walks the tree 9 % cheaper per ray — and nothing more from 96 or 128 Mi (profiles/r2_experiments_ab.txt)
-        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 64.0 * 1024 * 1024);
+        // up to 128 Mi slots = 26.8 GB of path state (of 288 GB), cut into two sub-pools of 64 Mi for worlds whose lean kernels run side by side (render_stream):
+        // a launch that carries twice the rays walks the tree 9 % cheaper per ray (round 2: cfg3 368 ms with 64 Mi in one pool against 392 with 32 Mi, nothing more
+        // from 96 or 128 Mi in ONE pool; round 4, two sub-pools: 351 / 340 / 341 ms with 64 / 96 / 128 Mi, profiles/r4_experiments_ab.txt).  A frame uses
+        // min(this, units / 8) slots, so small frames and a rank's share of a sharded frame stay small
+        c->st_slots = (uint32_t)env_double("ZR_STREAM_SLOTS", 128.0 * 1024 * 1024);
         // dynamic work units of shard s are handed out only by SHADE blocks with blockIdx % 64 == s (zr_stream.hip): a pool needs at
         // least 64 SHADE blocks (64 x 256 slots) or the units of the unserved shards would never be rendered
         c->st_slots = std::max<uint32_t>(64u * 256u, c->st_slots / 256 * 256);
@@ -1996,7 +1998,12 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     streams[0] = stream;
     for (int k = 1; k < ST_MAX_POOLS; k++) streams[k] = c->sub[k];
     const bool sharded = (size_t)plan.tiles.size() < (size_t)plan.tiles_x * plan.tiles_y;
-    const int pools = c->st_pools > 0 ? c->st_pools : (sharded ? 2 : 1);
+    // Two sub-pools, a fraction of a round apart on two streams, let one pool's SHADE run beside the other's EXTEND.  Until round 3 that paid on a rank's share only
+    // (the whole frame: 366.6 against 365.7 ms): SHADE needed 124 registers and found no room beside EXTEND's waves.  The lean builds of both kernels use 80
+    // (zr_stream.hip), a SIMD holds three waves of each, and a whole cfg3 frame gains 3.5 % with 64 Mi slots, 5.4 % with 128 Mi (profiles/r4_experiments_ab.txt); the
+    // general builds (demo: 128 + 117 registers) do not fit beside each other and lose 2 %: one pool for those
+    const bool lean_pair = s->leaf_level == 0 && s->ds.shade_lean != 0 && mode == 0;
+    const int pools = c->st_pools > 0 ? c->st_pools : ((sharded || lean_pair) ? 2 : 1);
     hipError_t e = zr::stream_render(s->ds, dc, de, seed, c->d_pool.p, P, spp, n_pix, c->d_pixels.p, c->d_partial.p, c->d_ctl.p,
                                      c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks, d_out, c->d_ctr.p, count != 0, streams, pools, c->st_event, &timer, c->h_active,
                                      keep_going, &rounds, s->leaf_level, mode, mode ? (void*)c->d_kend.p : nullptr, mode ? (void*)c->d_cls.p : nullptr, d_out2, mode ? c->d_cpart.p : nullptr, progress,
