@@ -3,7 +3,7 @@
 // never leaves the GPU: object boxes -> Morton keys -> radix sort -> PLOC merging (parallel locally-ordered clustering: every
 // cluster looks for its nearest neighbour, by merged surface area, within a window of the Morton order; mutual pairs merge;
 // repeat) -> SAH leaf collapse -> the 2->4 collapse onto 8-bit quantised 64-byte nodes -> sibling-pair records -> the primitive
-// records in leaf order.  The output is what the host path (zr_bvh.cpp + Flattener in zr_host.cpp) produces: the same arrays,
+// records in leaf order.  The output is what the host path (zr_bvh.cpp + Flattener in zr_flatten.h) produces: the same arrays,
 // another (equally valid) tree.  Closest hit does not depend on the tree.
 #pragma once
 #include <hip/hip_runtime_api.h>
@@ -32,7 +32,7 @@ struct BuildParams {
     float open_ratio = 1.25f;  // 4-wide collapse: a child is not opened when the wider node's grid would inflate a box's area beyond this
     int radius = 16;           // PLOC search radius (clusters on either side in Morton order)
     int top_clusters = 16384;  // PLOC stops at this many clusters and the host's binned-SAH builder arranges them (0: PLOC to the root); worlds under 8 x this: PLOC alone.
-                               // zr_host.cpp picks n / 64 within 4096 ... 65536
+                               // zr_commit.cpp picks n / 64 within 4096 ... 65536
 };
 
 // where a tree's leaves put their primitive records: the scene's final arrays and the first index this tree may use per leaf kind

@@ -24,7 +24,7 @@ struct BuildNode {
 // an array whose elements are NOT value-initialised by this process on allocation (the builder's threads touch the pages first:
 // zero-filling 160 MB of nodes from one thread costs more than building the tree).  CONTRACT: allocate() hands out memory that
 // READS AS ZERO until written — fresh anonymous mmap pages, which the kernel zero-fills on first touch.  The builder numbers its
-// nodes sparsely and the flattener (zr_host.cpp: index_nodes, emit_run, run_pairs) scans whole id ranges, classifying slots the
+// nodes sparsely and the flattener (zr_flatten.h: index_nodes, emit_run, run_pairs) scans whole id ranges, classifying slots the
 // builder never wrote as "neither leaf nor inner" because they are zero.  Whoever changes the allocator (a pool, a reused
 // mapping, malloc) must keep `zero_filled` true by clearing, or rewrite those scans as walks from the root.
 template <class T>

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -145,9 +146,23 @@ int zr_comm_gather_frame(zr_comm* c, void* d_frame, int W, int H, const zr_regio
         c->W = W; c->H = H; c->tile = ts; c->root_built = root;
     }
     if (c->root_built != root) { c->W = c->H = c->tile = 0; return zr_internal_fail(ZR_E_INVALID, "zr_comm_gather_frame: the root changed between calls on one communicator (destroy and recreate it)"); }
-    if (c->share == 0 || c->nranks == 1) return ZR_OK;
     const int ncclDouble = 8;
     int rc;
+    if (c->share != 0 && c->nranks == 1 && std::getenv("ZR_COMM_SELF_EXCHANGE")) {
+        // Rehearsal of the exchange on a one-GPU box: the whole path a non-root rank and the root take together — pack -> ncclSend / ncclRecv
+        // (to itself, inside one group) -> unpack — with the frame poisoned in between, so that what comes back can only have come through RCCL
+        hipError_t e = zr::launch_pack_tiles((const double*)d_frame, c->d_idx + c->first[0], c->count[0], c->d_packed, st);
+        if (e != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, hipGetErrorString(e));
+        if (hipMemsetAsync(d_frame, 0xFF, (size_t)W * H * 3 * sizeof(double), st) != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, "hipMemsetAsync failed");
+        if ((rc = g_rccl.GroupStart()) != 0) return nccl_fail("ncclGroupStart", rc);
+        if ((rc = g_rccl.Send(c->d_packed, c->count[0] * 3, ncclDouble, 0, c->comm, hip_stream)) != 0) { (void)g_rccl.GroupEnd(); return nccl_fail("ncclSend", rc); }
+        if ((rc = g_rccl.Recv(c->d_all, c->count[0] * 3, ncclDouble, 0, c->comm, hip_stream)) != 0) { (void)g_rccl.GroupEnd(); return nccl_fail("ncclRecv", rc); }
+        if ((rc = g_rccl.GroupEnd()) != 0) return nccl_fail("ncclGroupEnd", rc);
+        e = zr::launch_unpack_tiles((double*)d_frame, c->d_idx + c->first[0], c->count[0], c->d_all, st);
+        if (e != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, hipGetErrorString(e));
+        return ZR_OK;
+    }
+    if (c->share == 0 || c->nranks == 1) return ZR_OK;
     if (c->rank != root) {
         hipError_t e = zr::launch_pack_tiles((const double*)d_frame, c->d_idx + c->first[c->rank], c->count[c->rank], c->d_packed, st);
         if (e != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, hipGetErrorString(e));

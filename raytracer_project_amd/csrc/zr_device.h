@@ -417,7 +417,7 @@ __device__ inline void sphere_rec(const DScene& sc, uint32_t idx, const Ray& r, 
     V3 outward = vdiv(rec.p - center, s[3]);
     set_face(rec, r.d, outward);
     rec.mat = sc.sphere_mat[idx];
-    if (rec.mat != 0xFFFFFFFFu && (rec.mat & 0x80000000u)) { rec.mat &= 0x7FFFFFFFu; rec.front = true; }   // baked from under a translate (zr_host.cpp)
+    if (rec.mat != 0xFFFFFFFFu && (rec.mat & 0x80000000u)) { rec.mat &= 0x7FFFFFFFu; rec.front = true; }   // baked from under a translate (zr_flatten.h)
     if (!full && !mat_needs_uv(sc, rec.mat)) { rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0); return; }
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + 3.14159265358979323846;
@@ -446,7 +446,7 @@ __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r
     rec.p = p;
     rec.mat = (uint32_t)__double_as_longlong(v[18]);
     set_face(rec, r.d, smooth);
-    if ((uint32_t)__double_as_longlong(v[19]) & 1u) rec.front = true;   // baked from under a translate / rotate_y (zr_host.cpp)
+    if ((uint32_t)__double_as_longlong(v[19]) & 1u) rec.front = true;   // baked from under a translate / rotate_y (zr_flatten.h)
     // u, v, tangent, bitangent are not written by triangle::hit: fresh-record values
     rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
 }

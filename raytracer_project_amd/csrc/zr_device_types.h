@@ -1,4 +1,4 @@
-// zr_device_types.h — HBM data layout shared by the host (zr_host.cpp) and the kernels (zr_device.h).
+// zr_device_types.h — HBM data layout shared by the host (zr_commit.cpp, zr_render.cpp) and the kernels (zr_device.h).
 #pragma once
 #include <stdint.h>
 #include "../../include/zr_capi.h"

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(ZR_BLOCK) void path_records(DScene sc, DCamera cam,
     }
 }
 
-// ---- launch wrappers (called from zr_host.cpp) -------------------------------------------------------
+// ---- launch wrappers (called from zr_render.cpp) -------------------------------------------------------
 hipError_t launch_render(const DScene& sc, const DCamera& cam, const DEnv& env, uint64_t seed, const WorkDesc& wd, double* out,
                          unsigned long long* gctr, bool count, hipStream_t stream) {
     const int groups_per_block = ZR_BLOCK / wd.lanes_per_pixel;

@@ -911,7 +911,7 @@ __device__ __forceinline__ void brute_hit(const DScene& sc, const FusedObjs& fo,
         if (k == ZR_PRIM_SPHERE) h = sphere_t(q, ray, 0.001, tbest, t);
         else if (k == ZR_PRIM_TRIANGLE) h = triangle_t(q, ray, 0.001, tbest, t);
         else if (k == ZR_PRIM_CUBE) h = cube_t(q, ray, 0.001, tbest, t);
-        else if (k == ZR_KIND_PCUBE) h = pcube_t<false>(q, ray, 0.001, tbest, t);   // (no scaled placed cube reaches this kernel: zr_host.cpp finish_commit)
+        else if (k == ZR_KIND_PCUBE) h = pcube_t<false>(q, ray, 0.001, tbest, t);   // (no scaled placed cube reaches this kernel: zr_commit.cpp finish_commit)
         else h = medium_rec_t(q, ray, 0.001, tbest, g, t);
         if (h) { tbest = t; kbest = k; ibest = fo.index[i]; }
         if (COUNT) { if (k == ZR_PRIM_SPHERE) cn[0]++; else if (k == ZR_PRIM_TRIANGLE) cn[1]++; else if (k == ZR_PRIM_CUBE || k == ZR_KIND_PCUBE) cn[2]++; else cn[3]++; }

@@ -33,6 +33,9 @@ def owner_of_pixel(x, y, width, world, tile=TILE):
 
 def init_distributed(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).  Returns (rank, local_rank, world)."""
+    # dmabuf IPC: RCCL between processes (and CUDA-tensor sharing) needs it on this host driver, and it must be in the environment before the first
+    # HIP call of the process — a launcher that starts the ranks itself (torch.distributed.run by the driver) never passes through bench.self_launch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -48,10 +51,11 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
-def reduce_frame(acc, world, dst=0):
+def reduce_frame(acc, world, dst=0, _force=False):
     """The one collective of a frame: sum the per-rank accumulators (disjoint tiles) onto rank `dst`.
-    With the gloo backend (rehearsals on a box without one GPU per rank) device tensors are staged through the host."""
-    if world <= 1:
+    With the gloo backend (rehearsals on a box without one GPU per rank) device tensors are staged through the host.
+    `_force` (tests): run the collective even in a world of one, so that a one-GPU box executes `dist.reduce` on RCCL."""
+    if world <= 1 and not _force:
         return acc
     import torch.distributed as dist
     if dist.get_backend() == "gloo" and acc.is_cuda:
@@ -80,12 +84,14 @@ def owned_pixels(height, width, world, device, tile=TILE):
     return _owned[key]
 
 
-def gather_frame(acc, world, dst=0, tile=TILE):
+def gather_frame(acc, world, dst=0, tile=TILE, _force=False):
     """The one collective of a frame: a GATHER of every rank's packed tiles (1/world of the frame each, padded to the
     largest share) onto rank `dst`, which scatters them into `acc`.  Only `dst` needs the frame, so only `dst` receives:
     each share crosses one xGMI link once (round 2 used an all-gather, which also delivered 7 shares to each of the 7 ranks
-    that dropped them).  Pure data movement: bit-exact."""
-    if world <= 1:
+    that dropped them).  Pure data movement: bit-exact.
+    `_force` (tests): run pack -> dist.gather -> scatter even in a world of one (the root then also scatters its own share back), so that a
+    one-GPU box executes the exchange on the RCCL backend."""
+    if world <= 1 and not _force:
         return acc
     import torch
     import torch.distributed as dist
@@ -101,8 +107,10 @@ def gather_frame(acc, world, dst=0, tile=TILE):
     shares = [torch.empty((m, 3), dtype=frame.dtype, device=frame.device) for _ in range(world)] if rank == dst else None
     dist.gather(packed, shares, dst=dst)
     if rank == dst:
+        if _force:
+            flat[own[rank]] = float("nan")   # what comes back below can only have come through the collective
         for r in range(world):
-            if r != rank:
+            if r != rank or _force:
                 flat[own[r]] = shares[r][:own[r].numel()]
         if staged:
             acc.copy_(frame)

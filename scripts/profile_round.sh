@@ -51,7 +51,7 @@ for k in sorted(set(fa) | set(wa) | set(th) | set(d_fma)):
     if dn.get(k, 0):
         # wave-level instruction counts: an FP64 FMA is 2 flops on each of 64 lanes (inactive lanes are counted too: an upper bound on useful work)
         res['kernels'][k].update({'SQ_INSTS_VALU_FMA_F64': d_fma.get(k, 0.0), 'SQ_INSTS_VALU_MUL_F64': d_mul.get(k, 0.0), 'SQ_INSTS_VALU_ADD_F64': d_add.get(k, 0.0),
-                                  'SQ_INSTS_VALU': d_all.get(k, 0.0), 'GRBM_GUI_ACTIVE': d_gui.get(k, 0.0),
+                                  'SQ_INSTS_VALU': d_all.get(k, 0.0), 'GRBM_GUI_ACTIVE': d_gui.get(k, 0.0), 'valu_insts_per_launch': d_all.get(k, 0.0) / dn[k],
                                   # share of the chip's vector issue slots the kernel used: a wave64 VALU instruction occupies its SIMD for 4 cycles;
                                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs on the chip
                                   'valu_issue_frac': round(4.0 * d_all.get(k, 0.0) / (d_gui[k] / 8.0 * 1024.0), 4) if d_gui.get(k, 0) else None,

@@ -868,6 +868,75 @@ def test_cxx_host_collective_single_rank(ctx):
     lib.zr_comm_destroy(comm)
 
 
+def test_cxx_host_exchange_through_rccl_on_one_rank(ctx):
+    """zr_comm_gather_frame's whole exchange — pack -> ncclSend / ncclRecv (one group) -> unpack — executed on a one-GPU box: with
+    ZR_COMM_SELF_EXCHANGE the single rank sends its packed tiles to itself through RCCL; the frame is poisoned between pack and unpack."""
+    import ctypes as C
+    import torch
+    from raytracer_project_amd import capi
+    lib = ctx.lib
+    uid = (C.c_ubyte * 128)()
+    assert lib.zr_comm_unique_id(uid) == 0, lib.zr_last_error()
+    comm = lib.zr_comm_create(ctx._c, 1, 0, uid)
+    assert comm, lib.zr_last_error()
+    os.environ["ZR_COMM_SELF_EXCHANGE"] = "1"
+    try:
+        for (W, H, tile) in ((64, 48, 0), (70, 50, 20), (1920, 1080, 32)):
+            frame = (torch.arange(3 * W * H, dtype=torch.float64, device="cuda").reshape(H, W, 3) + 1) * 0.25
+            want = frame.clone()
+            reg = capi.Region(0, 0, 0, 0, tile, 0, 0, 0)
+            assert lib.zr_comm_gather_frame(comm, C.c_void_p(frame.data_ptr()), W, H, C.byref(reg), 0, None) == 0, lib.zr_last_error()
+            torch.cuda.synchronize()
+            assert torch.equal(frame, want), (W, H, tile)
+    finally:
+        del os.environ["ZR_COMM_SELF_EXCHANGE"]
+        lib.zr_comm_destroy(comm)
+
+
+def test_multi_exchange_on_the_nccl_backend_world_of_one():
+    """multi.gather_frame / reduce_frame as bench.py --gpus N runs them — torch.distributed on the `nccl` backend (= RCCL), device
+    tensors — executed on a one-GPU box: a process group of one rank, the `world <= 1` early-outs bypassed (`_force`).  Runs in a child process
+    (a process group is process-wide state)."""
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    worker = r'''
+import os, sys
+sys.path.insert(0, os.environ["ZR_ROOT"])
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+import torch, torch.distributed as dist
+from raytracer_project_amd import multi
+assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ
+rank, local, world = multi.init_distributed()          # before anything has touched the GPU: it must put the dmabuf-IPC setting into the environment
+assert (rank, world) == (0, 1) and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+for (H, W, tile) in ((48, 64, 32), (50, 70, 16), (1080, 1920, 32)):
+    full = (torch.arange(H * W * 3, dtype=torch.float64, device="cuda").reshape(H, W, 3) + 1) * 0.5
+    acc = full.clone()
+    multi.gather_frame(acc, 1, 0, tile, _force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, full), ("gather", H, W, tile)
+    acc = full.clone()
+    multi.reduce_frame(acc, 1, 0, _force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, full), ("reduce", H, W)
+vals = multi.all_reduce_values([1.5, 2.5], 1, torch.device("cuda", 0))
+assert vals == [1.5, 2.5]
+dist.destroy_process_group()
+print("nccl world-of-one ok")
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        f = os.path.join(tmp, "w.py")
+        open(f, "w").write(worker)
+        env = dict(os.environ, ZR_ROOT=ROOT, MASTER_PORT="29553")
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)   # init_distributed must set it itself
+        p = subprocess.run([sys.executable, f], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "nccl world-of-one ok" in p.stdout, p.stdout + p.stderr
+
+
 def test_cxx_host_collective_two_ranks():
     """zr_comm_gather_frame / zr_comm_reduce_frame between two processes on two GPUs (ids exchanged over a gloo group).  Needs a
     node with at least two devices: skipped on the one-GPU test box."""
