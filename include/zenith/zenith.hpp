@@ -858,12 +858,25 @@ inline size_t flatten_triangle_run(scene_builder& b, size_t n, Get&& get) {
 inline void hittable_list::flatten(zenith::scene_builder& b) const {
     const size_t N = objects.size();
     b.reserve_hint(N);
-    size_t i = 0;
+    // The bulk path costs O(n) for the n entries it is offered (staging array, array growth, thread start) whatever it takes of them, so it is offered only what
+    // it will probably take (offered the whole remaining list after every non-triangle member, a long MIXED list cost O(N^2)): a cheap serial look at
+    // the next 16384 entries qualifies a run — a shorter run is flattened one by one without being looked at again — and the window offered grows only while
+    // the run keeps filling it.
+    size_t i = 0, window = 65536;
     while (i < N) {
-        const size_t took = zenith::flatten_triangle_run(b, N - i, [&](size_t k) -> const hittable& { return *objects[i + k]; });
+        const size_t qmax = std::min<size_t>(N - i, 16384);
+        size_t q = 0;
+        for (; q < qmax; q++) { const hittable& h = *objects[i + q]; if (typeid(h) != typeid(triangle)) break; }
+        size_t took = 0;
+        if (q == 16384) {
+            const size_t n = std::min(N - i, window);
+            took = zenith::flatten_triangle_run(b, n, [&](size_t k) -> const hittable& { return *objects[i + k]; });
+            window = (took == n) ? std::min<size_t>(window * 4, N) : 65536;
+        }
         if (took) { i += took; continue; }
-        objects[i]->flatten(b);   // (not a long run of triangles, or a builder that wants them one by one)
-        i++;
+        const size_t one_by_one = std::max<size_t>(q, 1);   // a short run of triangles and / or one other member (or a builder that wants them one by one)
+        for (size_t k = 0; k < one_by_one; k++) objects[i + k]->flatten(b);
+        i += one_by_one;
     }
 }
 

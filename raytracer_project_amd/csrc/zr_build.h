@@ -78,8 +78,10 @@ public:
     // d_objects == nullptr: the entries are the bare triangles first_triangle + k (a zr_group's run).
     // root_in_array: the root becomes quads[0] (a group's tree) instead of BuiltTree::root.
     // d_run_demand: per group its tree's stack demand (world tree with placements), may be null.
-    // Returns hipErrorInvalidValue when the input is outside what this builder handles (the caller then uses the host builder):
-    // n < 2 is handled; non-finite or > 1e18 coordinates and trees deeper than depth_limit are not.
+    // An input outside what this builder handles — non-finite or > 1e18 coordinates, a tree deeper than depth_limit (n < 2 is handled) — makes build()
+    // return an error AND wants_host() true: the caller then uses the host builder.  Any other error is a genuine failure (error() says which), except that a
+    // caller may also treat hipErrorOutOfMemory as "use the host builder": the device build keeps the scene as given, its arena and the final arrays alive at
+    // once, several times the host path's footprint.
     hipError_t build(const BuildSceneIn& in, const zr_object* d_objects, const uint8_t* d_code, uint32_t first_triangle, uint32_t n,
                      const BuildParams& prm, bool root_in_array, const BuildPrimOut& out, const uint32_t* d_run_demand,
                      uint32_t depth_limit, bool stats, BuiltTree& t);
@@ -88,6 +90,7 @@ public:
     // placements: root / qroot of every instance from its group (after the groups' offsets are known)
     hipError_t patch_instances(DInstance* insts, const uint32_t* inst_group, uint32_t n, const uint32_t* d_run_root, const uint32_t* d_run_qroot);
     const char* error() const { return err_; }
+    bool wants_host() const { return use_host_; }
     // memory the built trees live in until relocate(): owned by the builder
     void* alloc_keep(size_t bytes);
 private:
@@ -95,6 +98,7 @@ private:
     unsigned char* arena_ = nullptr; size_t arena_bytes_ = 0;
     std::vector<void*> keep_;
     const char* err_ = "";
+    bool use_host_ = false;
 };
 
 }  // namespace zr

@@ -812,7 +812,8 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
                                 const BuildParams& bp, bool root_in_array, const BuildPrimOut& out, const uint32_t* d_run_demand, uint32_t depth_limit,
                                 bool stats, BuiltTree& t) {
     hipError_t e;
-    if (n == 0) { err_ = "empty tree"; return hipErrorInvalidValue; }
+    err_ = ""; use_host_ = false;
+    if (n == 0) { err_ = "empty tree"; use_host_ = true; return hipErrorInvalidValue; }
     Params prm;
     prm.ct = bp.ct; prm.max_leaf = bp.max_leaf < 1 ? 1 : (bp.max_leaf > 16 ? 16 : bp.max_leaf); prm.open_ratio = bp.open_ratio;
     prm.radius = bp.radius < 1 ? 1 : (bp.radius > MAX_R ? MAX_R : bp.radius);
@@ -883,7 +884,7 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     uint32_t h_state[8];
     if ((e = hipMemcpyAsync(h_state, state + 8, 8 * 4, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;
-    if (h_state[6] != 0) { err_ = "an object's box is not finite or beyond 1e18: host builder"; return hipErrorInvalidValue; }
+    if (h_state[6] != 0) { err_ = "an object's box is not finite or beyond 1e18: host builder"; use_host_ = true; return hipErrorInvalidValue; }
     const uint32_t top = (bp.top_clusters > 1 && (uint64_t)n >= 8ull * (uint64_t)bp.top_clusters) ? (uint32_t)bp.top_clusters : 1u;
     while (n_cur > top) {
         const uint32_t nb = (n_cur + 255) / 256;
@@ -964,7 +965,7 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
         if ((e = hipMemcpyAsync(h_state, state + 16, 8, hipMemcpyDeviceToHost, st_)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(st_)) != hipSuccess) return e;
         t.depth = h_state[0];
-        if (t.depth >= depth_limit) { err_ = "device tree deeper than the traversal stack allows: host builder"; return hipErrorInvalidValue; }
+        if (t.depth >= depth_limit) { err_ = "device tree deeper than the traversal stack allows: host builder"; use_host_ = true; return hipErrorInvalidValue; }
         if (h_root_meta & M_UNIFORM) {
             const uint32_t k = h_root_meta & M_KIND;
             h_cnt[k] = n;

@@ -222,8 +222,16 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
     out.cubes = s->d_cubes.p; out.cube_mat = s->d_cube_mat.p; out.pcubes = s->d_pcubes.p; out.pcube_mat = s->d_pcube_mat.p;
     out.insts = s->d_insts.p; out.inst_group = d_inst_group.p;
     auto builder = std::make_shared<zr::DeviceBuilder>(st);
+    // explicit outcome (hipErrorInvalidValue used to be the signal): the builder says when the input is the host builder's business; running out
+    // of memory is too — the device build's footprint is several times the host path's, whose arrays this function's buffers make room for when it returns
     auto build_fail = [&](hipError_t e) {
-        if (e == hipErrorInvalidValue) { std::fprintf(stderr, "[zr] device BVH build: %s\n", builder->error()); return (int)ZR_FALLBACK_HOST; }
+        if (builder->wants_host()) { std::fprintf(stderr, "[zr] device BVH build: %s\n", builder->error()); return (int)ZR_FALLBACK_HOST; }
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            std::fprintf(stderr, "[zr] device BVH build: out of device memory (%s): host builder\n", builder->error());
+            builder.reset();
+            return (int)ZR_FALLBACK_HOST;
+        }
         return fail(ZR_E_DEVICE, "device BVH build failed: %s (%s)", hipGetErrorString(e), builder->error());
     };
     // 3. the groups' trees (two-level BVH: one tree per shared run of triangles, in its own space)
@@ -349,7 +357,7 @@ int commit_device(zr_scene* s, const std::vector<zr_object>& objs, bool commit_s
         std::swap(t->a0, r_sph); std::swap(t->a1, r_tri_v); std::swap(t->a2, r_tri_n); std::swap(t->a3, r_cubes); std::swap(t->a4, r_gbox);
         std::swap(t->u0, r_sph_mat); std::swap(t->u1, r_tri_mat); std::swap(t->u2, r_cube_mat); std::swap(t->u3, d_inst_group); std::swap(t->u4, d_run_demand);
         std::swap(t->u5, d_run_root); std::swap(t->u6, d_run_qroot); std::swap(t->m, r_media); std::swap(t->o, r_objs); std::swap(t->c, r_code);
-        try { std::thread([t]() mutable { (void)hipSetDevice(t->device); t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
+        s->ctx->free_later([t]() mutable { (void)hipSetDevice(t->device); t.reset(); });
     }
     phase("release");
     return ZR_OK;
@@ -362,12 +370,12 @@ extern "C" {
 zr_scene* zr_scene_create(zr_ctx* c) {
     if (!c) { fail(ZR_E_INVALID, "null context"); return nullptr; }
     zr_scene* s = new zr_scene();
-    s->ctx = c;
+    s->ctx = c; s->device = c->device;
     return s;
 }
 void zr_scene_destroy(zr_scene* s) {
     if (!s) return;
-    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    (void)hipSetDevice(s->device);   // (not through s->ctx: the context may be gone)
     delete s;
 }
 
@@ -514,7 +522,11 @@ int zr_scene_commit(zr_scene* s) {
             CommitSummary cs;
             rc = commit_device(s, objs, commit_stats, cs);
             if (rc == ZR_OK) return finish_commit(s, cs, objs.size());
-            if (rc != ZR_FALLBACK_HOST) return rc;
+            // the device build holds the scene as given, its arena and the final arrays at once: when one of ITS allocations does not fit, the host path
+            // (whose staging lives in host memory) may still commit the world
+            const bool oom = rc == ZR_E_DEVICE && std::strstr(zr_host::last_error(), "out of device memory") != nullptr;
+            if (rc != ZR_FALLBACK_HOST && !oom) return rc;
+            if (oom) std::fprintf(stderr, "[zr] device BVH build: %s: host builder\n", zr_host::last_error());
             phase("device build refused");
         }
     }
@@ -640,7 +652,7 @@ int zr_scene_commit(zr_scene* s) {
         auto t = std::make_shared<Trash>();
         fl.after_primitives = nullptr;   // (it captures locals of this call)
         t->fl = std::move(flp); t->br = std::move(br); t->boxes = std::move(boxes); t->objs = std::move(objs); t->kinds = std::move(kinds); t->baked = std::move(baked); t->runs = std::move(runs);
-        try { std::thread([t]() mutable { t.reset(); }).detach(); } catch (...) { /* no thread: freed here */ }
+        s->ctx->free_later([t]() mutable { t.reset(); });
     }
     phase("release");
     return ZR_OK;

@@ -67,6 +67,7 @@ zr_ctx* zr_create(int device_ordinal) {
 
 void zr_destroy(zr_ctx* c) {
     if (!c) return;
+    c->drain_trash();
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);

@@ -141,6 +141,16 @@ struct zr_ctx {
     double last_render_ms = 0;        // sum over the launches of the most recent render call
     hipStream_t last_stream = nullptr;
     bool last_counted = false;
+    // memory a commit frees off the caller's clock (staging arrays, the device builder's arena): at most one such thread is outstanding, and zr_destroy joins it —
+    // a detached thread could still be inside hipFree while the process tears the HIP runtime down
+    std::mutex trash_m;
+    std::thread trash;
+    template <class F> void free_later(F&& f) {
+        std::lock_guard<std::mutex> lk(trash_m);
+        if (trash.joinable()) trash.join();
+        try { trash = std::thread(std::forward<F>(f)); } catch (...) { f(); }
+    }
+    void drain_trash() { std::lock_guard<std::mutex> lk(trash_m); if (trash.joinable()) trash.join(); }
 };
 
 // one input array of a scene: the library's own copy (zr_scene_set_*) or a view of the caller's memory (zr_scene_set_all_borrowed)
@@ -161,6 +171,7 @@ struct HostArray {
 
 struct zr_scene {
     zr_ctx* ctx = nullptr;
+    int device = 0;               // the context's device ordinal, kept here so that zr_scene_destroy needs no live context (a scene may outlive its context)
     // host side of the world as given: copies, or borrowed views until the commit
     HostArray<double> spheres, tri_v, tri_n, cubes;
     HostArray<uint32_t> sphere_mat, tri_mat, cube_mat;

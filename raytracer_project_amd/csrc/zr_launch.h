@@ -53,7 +53,7 @@ hipError_t stream_render(const DScene& sc, const DCamera& cam, const DEnv& env, 
 // loads, so an object's record reaches every lane of a wave through SGPRs — no vector memory instruction, no VGPRs per lane for
 // data that is the same in all of them (reading the records through the scene's pointers, the compiler issued 255 vector loads
 // in the loop and spilled; the pointers come out of a struct, so it cannot prove the addresses uniform and read-only).
-// rec: sphere cx cy cz r | triangle 9 vertices | cube 6 | placed cube 12 | plain medium: boundary (sphere 4 / cube 6), [6] = -1/density,
+// rec: sphere cx cy cz r | triangle 9 vertices | cube 6 | placed cube 16 (ZR_PCUBE_STRIDE) | plain medium: boundary (sphere 4 / cube 6), [6] = -1/density,
 // [7] = id bits, [8] = boundary type bits.
 #define ZR_FUSED_OBJECTS 16
 struct FusedObjs {

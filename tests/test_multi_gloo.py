@@ -63,7 +63,8 @@ def test_tile_sharding_gloo(exchange, world, tile, built, tmp_path):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), str(script)]
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        if p.returncode == 0:
+        lost_port = any(m in (p.stdout + p.stderr).lower() for m in ("address already in use", "eaddrinuse", "errno: 98"))
+        if p.returncode == 0 or not lost_port:   # (only a lost rendezvous port is retried — a rank that crashed or disagreed fails the first time)
             break
     assert p.returncode == 0, p.stdout + p.stderr
     tiles = sorted(int(l.split()[-1]) for l in p.stdout.splitlines() if l.startswith("rank"))
