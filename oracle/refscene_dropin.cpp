@@ -9,6 +9,9 @@
 // scene code (oracle/_ref/zenith_ref, scene "refdemo"), bit for bit.
 //   refscene_dropin tile <x0> <y0> <w> <h> <spp> <out.npy>      radiance tile through the CPU restatement
 //   refscene_dropin stats                                        object counts of the flattened world
+//   refscene_dropin dump <prefix>                                the flattened world itself — every array of the zr_scene_desc, camera, environment, seed — as
+//                                                                <prefix>_<name>.npy (structs as raw bytes): tests/golden/make_golden.py packs them into the
+//                                                                fixture the GPU test commits through the C ABI (the scene's assets never travel; its arrays do)
 #define ZENITH_STB_IMAGE
 #define STB_IMAGE_IMPLEMENTATION
 #include <unistd.h>
@@ -42,6 +45,19 @@ static void write_npy(const char* path, size_t h, size_t w, const double* data) 
     std::fclose(f);
 }
 
+// a 1-D array as .npy: descr "<f8" / "<u4" / "|u1", n elements of `size` bytes
+static void write_npy1(const std::string& path, const char* descr, size_t n, size_t size, const void* data) {
+    std::string hdr = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': (" + std::to_string(n) + ",), }";
+    size_t pad = (64 - (10 + hdr.size() + 1) % 64) % 64;
+    hdr += std::string(pad, ' ') + "\n";
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(2); }
+    unsigned char magic[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(hdr.size() & 255), (unsigned char)(hdr.size() >> 8)};
+    std::fwrite(magic, 1, 10, f); std::fwrite(hdr.data(), 1, hdr.size(), f);
+    if (n) std::fwrite(data, size, n, f);
+    std::fclose(f);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: refscene_dropin tile <x0> <y0> <w> <h> <spp> <out.npy> | stats\n"); return 2; }
     zr_demo_scene s;
@@ -54,6 +70,24 @@ int main(int argc, char** argv) {
     if (std::string(argv[1]) == "stats") {
         std::printf("{\"objects\": %zu, \"triangles\": %zu, \"spheres\": %zu, \"cubes\": %zu, \"media\": %zu, \"materials\": %zu, \"textures\": %zu, \"texel_bytes\": %zu, \"warnings\": %zu}\n",
                     fs.objects.size(), fs.tri_mat.size(), fs.sphere_mat.size(), fs.cube_mat.size(), fs.media.size(), fs.materials.size(), fs.textures.size(), fs.texels.size(), fs.warnings.size());
+        return 0;
+    }
+    if (std::string(argv[1]) == "dump") {
+        if (argc < 3) return 2;
+        const std::string pre = argv[2];
+        auto f8 = [&](const char* name, const double* p, size_t n) { write_npy1(pre + "_" + name + ".npy", "<f8", n, 8, p); };
+        auto u4 = [&](const char* name, const uint32_t* p, size_t n) { write_npy1(pre + "_" + name + ".npy", "<u4", n, 4, p); };
+        auto raw = [&](const char* name, const void* p, size_t bytes) { write_npy1(pre + "_" + name + ".npy", "|u1", bytes, 1, p); };
+        f8("spheres", d.spheres, d.n_spheres * 4); u4("sphere_mat", d.sphere_mat, d.n_spheres);
+        f8("tri_v", d.tri_v, d.n_tris * 9); f8("tri_n", d.tri_n, d.n_tris * 9); u4("tri_mat", d.tri_mat, d.n_tris);
+        f8("cubes", d.cubes, d.n_cubes * 12); u4("cube_mat", d.cube_mat, d.n_cubes);
+        raw("media", d.media, d.n_media * sizeof(zr_medium)); raw("ops", d.ops, d.n_ops * sizeof(zr_xform_op)); raw("objects", d.objects, d.n_objects * sizeof(zr_object));
+        raw("groups", d.groups, d.n_groups * sizeof(zr_group)); raw("materials", d.materials, d.n_materials * sizeof(zr_material));
+        raw("textures", d.textures, d.n_textures * sizeof(zr_texture)); raw("texels", d.texels, d.texel_bytes);
+        raw("camera", &s.cam, sizeof s.cam); raw("env", &env, sizeof env);
+        std::printf("{\"scene\": \"refdemo\", \"seed\": %llu, \"objects\": %zu, \"triangles\": %zu, \"spheres\": %zu, \"cubes\": %zu, \"media\": %zu, \"ops\": %zu, \"groups\": %zu, "
+                    "\"materials\": %zu, \"textures\": %zu, \"texel_bytes\": %zu}\n", (unsigned long long)s.seed, (size_t)d.n_objects, (size_t)d.n_tris, (size_t)d.n_spheres, (size_t)d.n_cubes,
+                    (size_t)d.n_media, (size_t)d.n_ops, (size_t)d.n_groups, (size_t)d.n_materials, (size_t)d.n_textures, (size_t)d.texel_bytes);
         return 0;
     }
     if (argc < 8) return 2;

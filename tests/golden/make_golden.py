@@ -18,6 +18,7 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.path.join(ROOT, "oracle", "_ref", "zenith_ref")
 
@@ -212,6 +213,33 @@ def make_kat(tmp):
     print("kat_kat0", {k: v.shape for k, v in arrays.items()})
 
 
+def make_refdemo(tmp):
+    """The reference's OWN demo world (load_materials + sceneAssetsLoader + build_geometry, scene_management.hpp:28-236) for the GPU: the scene reads the
+    reference's assets/ at run time, which never travel — so the world travels FLATTENED.  oracle/_ref/refscene_dropin (the reference's scene code compiled
+    unchanged against the drop-in) dumps every array of the zr_scene_desc it flattens to (decoded texels included), oracle/_ref/zenith_ref (the same scene
+    code against the reference's own headers) renders the full frame at 8 spp and two tiles at the scene's 16 spp.  tests/test_refdemo_gpu.py commits the
+    arrays through the C ABI and compares."""
+    from refdemo_assets import asset_dir
+    dropin = os.path.join(ROOT, "oracle", "_ref", "refscene_dropin")
+    os.makedirs(os.path.join(tmp, "refdemo_cwd"))
+    cwd = asset_dir(os.path.join(tmp, "refdemo_cwd"))
+    pre = os.path.join(tmp, "refdemo_d")
+    p = subprocess.run([dropin, "dump", pre], cwd=cwd, capture_output=True, text=True, check=True)
+    meta = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    names = ["spheres", "sphere_mat", "tri_v", "tri_n", "tri_mat", "cubes", "cube_mat", "media", "ops", "objects", "groups", "materials", "textures", "texels", "camera", "env"]
+    arrays = {n: np.load(f"{pre}_{n}.npy") for n in names}
+    np.savez_compressed(os.path.join(HERE, "refdemo_scene.npz"), meta=np.array(json.dumps(meta)), **arrays)
+    print("refdemo_scene", meta)
+    frames = {}
+    for name, (x0, y0, w, h, spp) in {"full8": (0, 0, 640, 360, 8), "tile_a": (40, 250, 24, 16, 16), "tile_b": (300, 150, 32, 24, 16)}.items():
+        out = os.path.join(tmp, "refdemo_" + name)
+        r = subprocess.run([REF, "tile", "refdemo", str(x0), str(y0), str(w), str(h), str(spp), str(os.cpu_count() or 1), out, "0"], cwd=cwd, capture_output=True, text=True, check=True)
+        m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        frames[name] = np.load(out + "_mean.npy"); frames[name + "_meta"] = np.array(json.dumps(m))
+        print("refdemo", name, m)
+    np.savez_compressed(os.path.join(HERE, "refdemo_frames.npz"), **frames)
+
+
 def run(*args):
     p = subprocess.run([REF] + [str(a) for a in args], capture_output=True, text=True, check=True)
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -282,6 +310,8 @@ def main():
                 arrays["hist"] = np.load(pre + "_hist.npy")
             np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=np.array(json.dumps(metas)), **arrays)
             print(name, [m["preset"] for m in metas])
+        if not want or "refdemo" in want:
+            make_refdemo(tmp)
         if not want or "kat" in want or "kat0" in want:
             make_kat(tmp)
         if not want or "texels" in want:

@@ -582,8 +582,12 @@ def test_bench_line_contract(built):
     assert rf["bound"] in ("fp64-valu", "l2-request-rate", "hbm") and rf["bound"] == "fp64-valu" and rf["kernel"] == "fused_render"
     assert d["config"]["render_path"] == "fused small-scene kernel" and d["config"]["bvh_builder"].startswith(("host", "device"))
     assert d["config"]["bvh_build_upload_s"] >= 0 and d["config"]["bvh_build_upload_first_s"] >= 0
-    assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "76 B per hit" in rf["model"] and "NOT" in rf["model"]
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0 and rf["launches_timed"] > 0
+    # a register-resident kernel is not under the HBM ceiling: `frac` is its share of the chip's vector issue rate (from the counter file of the current kernel
+    # source: null without one — never a fraction of a ceiling the kernel is not under), the HBM-model figure stays beside it
+    assert rf["unit"] == "G wave-instructions/s" and abs(rf["peak"] - 614.4) < 1e-6 and "76 B per hit" in rf["model"] and "NOT" in rf["model"]
+    assert rf["frac"] is None or (0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4)
+    assert abs(rf["frac_hbm_model"] - rf["achieved_hbm_model"] / 8000.0) < 1e-4 and rf["kernel_ms"] > 0 and rf["launches_timed"] > 0
+    assert rf["co_running"] is False and d["per_rank_ms_per_step"]["min"] > 0
     cb = d["cpu_baseline"]
     assert cb["value"] and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
     if cb["kind"] == "reference":   # the reference's best thread count (at most 16), median of three runs; the all-cores figure beside it

@@ -12,6 +12,7 @@ that see it are not reproducible even between two reference builds, so the compa
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -23,25 +24,8 @@ BIN_REF = os.path.join(ROOT, "oracle", "_ref", "zenith_ref")
 BIN_DROPIN = os.path.join(ROOT, "oracle", "_ref", "refscene_dropin")
 
 
-def _asset_dir(tmp):
-    """a working directory with the reference's assets/ tree (symlinks) plus a generated teapot.obj"""
-    for sub in ("bump_maps", "textures"):
-        os.makedirs(os.path.join(tmp, "assets"), exist_ok=True)
-        os.symlink(os.path.join(REF, "assets", sub), os.path.join(tmp, "assets", sub))
-    os.makedirs(os.path.join(tmp, "assets", "models"))
-    for f in os.listdir(os.path.join(REF, "assets", "models")):
-        os.symlink(os.path.join(REF, "assets", "models", f), os.path.join(tmp, "assets", "models", f))
-    with open(os.path.join(tmp, "assets", "models", "teapot.obj"), "w") as f:   # a small lathe body: quads, no normals
-        n, rings = 24, [(0.0, 0.0), (1.2, 0.0), (1.6, 0.8), (1.3, 1.6), (0.5, 2.0), (0.0, 2.1)]
-        for r, y in rings:
-            for k in range(n):
-                a = 2 * np.pi * k / n
-                f.write("v %.6f %.6f %.6f\n" % (r * np.cos(a), y, r * np.sin(a)))
-        for j in range(len(rings) - 1):
-            for k in range(n):
-                a, b = j * n + k + 1, j * n + (k + 1) % n + 1
-                f.write("f %d %d %d %d\n" % (a, b, b + n, a + n))
-    return tmp
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from refdemo_assets import asset_dir as _asset_dir   # (shared with tests/golden/make_golden.py, which makes the fixtures of tests/test_refdemo_gpu.py)
 
 
 @pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists(BIN_REF) and os.path.exists(BIN_DROPIN)),
