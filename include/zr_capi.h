@@ -168,7 +168,10 @@ typedef struct zr_region {
     int32_t tile_size; /* 0 = default (32) */
     int32_t tile_mod;  /* 0 or 1 = every tile */
     int32_t tile_rem;
-    int32_t pad_;
+    int32_t tile_skew; /* 0: tile t (row-major index) belongs to the part t % tile_mod; s > 0: tile (tx, ty) belongs to (tx + s * ty) % tile_mod — a lattice
+                          instead of the near-vertical stripes t % tile_mod makes when the tiles per row are a multiple of tile_mod / 2 (1920 / 32 = 60 tiles per
+                          row over 8 ranks: a rank then owns the same two tile columns in every row, and the ranks under the middle of the picture are 4 %
+                          slower than the others; with skew 3: round 4, profiles/r4_shards.txt).  (This word was padding until round 4: 0 keeps the old map.) */
 } zr_region;
 
 /* counters of the last zr_render on a context (collected only when `collect_counters` was set:

@@ -827,11 +827,11 @@ int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t
     const Scene& sc = *(Scene*)scene;
     Cam cam; cam.c = *cam_in; cam.initialize();
     const int W = cam.c.image_width, H = cam.c.image_height, spp = cam.c.samples_per_pixel;
-    int x0 = 0, y0 = 0, w = W, h = H, ts = 32, tmod = 1, trem = 0;
+    int x0 = 0, y0 = 0, w = W, h = H, ts = 32, tmod = 1, trem = 0, tskew = 0;
     if (region) {
         if (region->w > 0 && region->h > 0) { x0 = region->x0; y0 = region->y0; w = region->w; h = region->h; }
         if (region->tile_size > 0) ts = region->tile_size;
-        if (region->tile_mod > 1) { tmod = region->tile_mod; trem = region->tile_rem; }
+        if (region->tile_mod > 1) { tmod = region->tile_mod; trem = region->tile_rem; tskew = region->tile_skew > 0 ? region->tile_skew : 0; }
     }
     if (x0 < 0 || y0 < 0 || x0 + w > W || y0 + h > H) return ZR_E_INVALID;
     const int tiles_x = (W + ts - 1) / ts;
@@ -845,7 +845,11 @@ int zro_render(void* scene, const zr_camera* cam_in, const zr_env* env, uint64_t
             int j = y0 + jj;
             for (int ii = 0; ii < w; ii++) {
                 int i = x0 + ii;
-                if (tmod > 1) { int t = (j / ts) * tiles_x + (i / ts); if (t % tmod != trem) continue; }
+                if (tmod > 1) {   // zr_region: tile t belongs to part t % tile_mod, or with a skew tile (tx, ty) to (tx + skew ty) % tile_mod
+                    const int tx = i / ts, ty = j / ts;
+                    const int part = tskew > 0 ? (int)(((long long)tx + (long long)tskew * ty) % tmod) : (ty * tiles_x + tx) % tmod;
+                    if (part != trem) continue;
+                }
                 V3 acc(0, 0, 0);
                 for (int s = 0; s < spp; s++) {
                     Rng g; g.key = zr_stream_key(seed, (uint64_t)j * W + i, (uint64_t)s);

@@ -65,7 +65,7 @@ class Camera(C.Structure):
 
 class Region(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("tile_size", C.c_int32),
-                ("tile_mod", C.c_int32), ("tile_rem", C.c_int32), ("pad_", C.c_int32)]
+                ("tile_mod", C.c_int32), ("tile_rem", C.c_int32), ("tile_skew", C.c_int32)]
 
 
 class PostParams(C.Structure):

@@ -67,7 +67,7 @@ hipError_t launch_unpack_tiles(double* frame, const uint32_t* idx, size_t n, con
 struct zr_comm {
     void* comm = nullptr; int device = 0; int nranks = 1, rank = 0;
     // packed-tile exchange: per rank the flat pixel indices (y * W + x, ascending) of the tiles it owns, cached per frame geometry
-    int W = 0, H = 0, tile = 0, root_built = 0;
+    int W = 0, H = 0, tile = 0, skew = 0, root_built = 0;
     std::vector<size_t> first, count;     // rank r owns idx[first[r] .. first[r] + count[r])
     size_t share = 0;                     // max over ranks of count[r]: the stride of the root's receive slots
     uint32_t* d_idx = nullptr; double* d_packed = nullptr; double* d_all = nullptr;
@@ -110,8 +110,9 @@ int zr_comm_gather_frame(zr_comm* c, void* d_frame, int W, int H, const zr_regio
     if (root < 0 || root >= c->nranks) return zr_internal_fail(ZR_E_INVALID, "root out of range");
     // The exchange moves tile t of the whole frame from rank t % nranks: the region this rank rendered with must be exactly that
     // partition, or the root's pixels would be overwritten by pixels nobody rendered.
-    int ts = 32;
+    int ts = 32, skew = 0;
     if (region) {
+        skew = region->tile_skew > 0 ? region->tile_skew : 0;
         if (region->tile_size > 0) ts = region->tile_size;
         const bool whole = (region->w <= 0 || region->h <= 0) || (region->x0 == 0 && region->y0 == 0 && region->w == W && region->h == H);
         const int mod = region->tile_mod > 1 ? region->tile_mod : 1, rem = region->tile_mod > 1 ? region->tile_rem : 0;
@@ -121,12 +122,16 @@ int zr_comm_gather_frame(zr_comm* c, void* d_frame, int W, int H, const zr_regio
     if (ts > 1024) return zr_internal_fail(ZR_E_INVALID, "bad tile size");
     if (hipSetDevice(c->device) != hipSuccess) return zr_internal_fail(ZR_E_DEVICE, "hipSetDevice failed");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (W != c->W || H != c->H || ts != c->tile) {   // (re)build the ownership lists: tile t = (y / ts) * tiles_x + x / ts belongs to rank t % nranks
+    if (W != c->W || H != c->H || ts != c->tile || skew != c->skew) {   // (re)build the ownership lists: tile t = (y / ts) * tiles_x + x / ts belongs to rank t % nranks
         c->release();
         const int tiles_x = (W + ts - 1) / ts;
         std::vector<std::vector<uint32_t>> own((size_t)c->nranks);
         for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) own[(size_t)(((y / ts) * tiles_x + x / ts) % c->nranks)].push_back((uint32_t)((size_t)y * W + x));
+            for (int x = 0; x < W; x++) {
+                const int tx = x / ts, ty = y / ts;
+                const int part = skew > 0 ? (int)(((long long)tx + (long long)skew * ty) % c->nranks) : (ty * tiles_x + tx) % c->nranks;
+                own[(size_t)part].push_back((uint32_t)((size_t)y * W + x));
+            }
         c->first.assign((size_t)c->nranks, 0); c->count.assign((size_t)c->nranks, 0); c->share = 0;
         std::vector<uint32_t> flat; flat.reserve((size_t)W * H);
         for (int r = 0; r < c->nranks; r++) {
@@ -143,7 +148,7 @@ int zr_comm_gather_frame(zr_comm* c, void* d_frame, int W, int H, const zr_regio
             c->release(); c->W = c->H = c->tile = 0;
             return zr_internal_fail(ZR_E_DEVICE, "zr_comm_gather_frame: out of device memory");
         }
-        c->W = W; c->H = H; c->tile = ts; c->root_built = root;
+        c->W = W; c->H = H; c->tile = ts; c->skew = skew; c->root_built = root;
     }
     if (c->root_built != root) { c->W = c->H = c->tile = 0; return zr_internal_fail(ZR_E_INVALID, "zr_comm_gather_frame: the root changed between calls on one communicator (destroy and recreate it)"); }
     const int ncclDouble = 8;

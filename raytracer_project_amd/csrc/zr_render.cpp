@@ -68,21 +68,22 @@ struct Plan {
 int make_plan(const zr_camera& cam, const zr_region* region, Plan& p) {
     p.W = cam.image_width < 1 ? 1 : cam.image_width;
     p.H = cam.image_height < 1 ? 1 : cam.image_height;
-    p.ts = 32; int mod = 1, rem = 0;
+    p.ts = 32; int mod = 1, rem = 0, skew = 0;
     p.x0 = 0; p.y0 = 0; p.x1 = p.W; p.y1 = p.H;
     if (region) {
         if (region->tile_size > 0) p.ts = region->tile_size;
-        if (region->tile_mod > 1) { mod = region->tile_mod; rem = region->tile_rem; }
+        if (region->tile_mod > 1) { mod = region->tile_mod; rem = region->tile_rem; skew = region->tile_skew; }
         if (region->w > 0 && region->h > 0) { p.x0 = region->x0; p.y0 = region->y0; p.x1 = region->x0 + region->w; p.y1 = region->y0 + region->h; }
     }
-    if (p.x0 < 0 || p.y0 < 0 || p.x1 > p.W || p.y1 > p.H || rem < 0 || rem >= mod || p.ts > 1024)
+    if (p.x0 < 0 || p.y0 < 0 || p.x1 > p.W || p.y1 > p.H || rem < 0 || rem >= mod || skew < 0 || p.ts > 1024)
         return fail(ZR_E_INVALID, "region outside the %dx%d frame or bad tile parameters", p.W, p.H);
     p.tiles_x = (p.W + p.ts - 1) / p.ts; p.tiles_y = (p.H + p.ts - 1) / p.ts;
     p.tiles.clear();
     for (int ty = p.y0 / p.ts; ty <= (p.y1 - 1) / p.ts; ty++)
         for (int tx = p.x0 / p.ts; tx <= (p.x1 - 1) / p.ts; tx++) {
             int t = ty * p.tiles_x + tx;
-            if (t % mod == rem) p.tiles.push_back(t);
+            const int part = skew > 0 ? (int)(((long long)tx + (long long)skew * ty) % mod) : t % mod;   // zr_region::tile_skew
+            if (part == rem) p.tiles.push_back(t);
         }
     int spp = cam.samples_per_pixel < 1 ? 1 : cam.samples_per_pixel;
     p.lanes = 64; while (p.lanes > spp) p.lanes >>= 1;

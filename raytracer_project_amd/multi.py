@@ -1,5 +1,5 @@
 """Pixel-tile sharding of one frame across the GPUs of a node: one process per GPU, scene replicated,
-interleaved 32x32 tiles (tile t -> rank t % world), and ONE collective per frame (torch.distributed backend
+interleaved 32x32 tiles (tile (tx, ty) -> rank (tx + skew * ty) % world: `tile_skew`), and ONE collective per frame (torch.distributed backend
 "nccl" = RCCL over xGMI): every rank packs the pixels of ITS tiles (1/world of the frame) and one gather hands
 the packed tiles to rank 0, which scatters them into the frame.  Each rank therefore sends 1/world of the double3 frame
 over each of its xGMI links (6.2 MB at 1080p and 8 ranks) instead of pushing the whole 49.8 MB frame — 7/8 of it
@@ -21,13 +21,33 @@ import os
 TILE = int(os.environ.get("ZR_MULTI_TILE", "32"))
 
 
+def tile_skew(world):
+    """The lattice the tiles are dealt on: tile (tx, ty) -> rank (tx + skew * ty) % world (zr_region::tile_skew).  The row-major rule t % world of rounds 1-3 gives
+    near-vertical stripes whenever the tiles per row are a multiple of world / 2 (1080p: 60 tiles per row, 8 ranks — a rank owned two tile columns of every
+    row, and the ranks under the middle of the picture were 4 % slower than the others); a skew near 0.38 * world that is coprime to world spreads every
+    rank's tiles over all columns and rows.  ZR_MULTI_SKEW overrides (0 = the old rule)."""
+    env = os.environ.get("ZR_MULTI_SKEW")
+    if env is not None:
+        return max(0, int(env))
+    if world <= 2:
+        return 1 if world == 2 else 0
+    from math import gcd
+    s = max(1, round(0.382 * world))
+    while gcd(s, world) != 1:
+        s += 1
+    return s
+
+
 def tile_region(capi, rank, world, tile=TILE):
     """The zr_region selecting this rank's tiles of the full frame."""
-    return capi.Region(0, 0, 0, 0, tile, world if world > 1 else 0, rank if world > 1 else 0, 0)
+    return capi.Region(0, 0, 0, 0, tile, world if world > 1 else 0, rank if world > 1 else 0, tile_skew(world) if world > 1 else 0)
 
 
 def owner_of_pixel(x, y, width, world, tile=TILE):
     tiles_x = (width + tile - 1) // tile
+    skew = tile_skew(world)
+    if skew > 0:
+        return ((x // tile) + skew * (y // tile)) % world
     return ((y // tile) * tiles_x + (x // tile)) % world
 
 
@@ -74,12 +94,14 @@ _owned = {}
 def owned_pixels(height, width, world, device, tile=TILE):
     """per rank: flat pixel indices (y * width + x, ascending) of the tiles it owns; cached"""
     import torch
-    key = (height, width, world, str(device), tile)
+    skew = tile_skew(world)
+    key = (height, width, world, str(device), tile, skew)
     if key not in _owned:
         ys = torch.arange(height, device=device).view(-1, 1)
         xs = torch.arange(width, device=device).view(1, -1)
         tiles_x = (width + tile - 1) // tile
-        owner = (torch.div(ys, tile, rounding_mode="floor") * tiles_x + torch.div(xs, tile, rounding_mode="floor")) % world
+        ty, tx = torch.div(ys, tile, rounding_mode="floor"), torch.div(xs, tile, rounding_mode="floor")
+        owner = ((tx + skew * ty) if skew > 0 else (ty * tiles_x + tx)) % world
         _owned[key] = [torch.nonzero(owner.reshape(-1) == r).reshape(-1) for r in range(world)]
     return _owned[key]
 

@@ -407,12 +407,13 @@ def test_tile_sharding_is_exact(ctx):
     full = sc.render(cam, ds.env, ds.seed, None)
     again = sc.render(cam, ds.env, ds.seed, None)
     assert np.array_equal(full, again), "render is not bit-reproducible"
-    acc = np.zeros_like(full)
-    for rank in range(3):
-        part = sc.render(cam, ds.env, ds.seed, capi.Region(0, 0, 0, 0, 32, 3, rank, 0))
-        assert not (acc != 0)[part != 0].any(), "tiles overlap between ranks"
-        acc += part
-    assert np.array_equal(acc, full)
+    for skew in (0, 2):   # the row-major rule t % 3 and the lattice (tx + 2 ty) % 3 (zr_region::tile_skew)
+        acc = np.zeros_like(full)
+        for rank in range(3):
+            part = sc.render(cam, ds.env, ds.seed, capi.Region(0, 0, 0, 0, 32, 3, rank, skew))
+            assert not (acc != 0)[part != 0].any(), "tiles overlap between ranks"
+            acc += part
+        assert np.array_equal(acc, full), skew
     assert np.isfinite(full).all() and (full >= 0).all() and 0.1 < full.mean() < 2.0
 
 
