@@ -596,6 +596,28 @@ def test_bench_line_contract(built):
         assert cb["cores"] <= 16 and len(cb["runs"]) == 3 and sorted(cb["runs"])[1] == cb["value"] and "reference_on_all_cores" in cb
 
 
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "cfg5", "demo"])
+def test_bench_line_names_its_bound_from_counters(built, workload):
+    """for every workload the bench can name, `roofline.bound` comes from a counter pass of the CURRENT kernel source
+    (profiles/r*_<workload>_traffic.json, keyed by bench.py --kernel-src-sha; scripts/profile_round.sh makes it) and `frac` is a fraction (<= 1) of the
+    ceiling the dominant kernel is under: the HBM peak for worlds beyond the L2s, the chip's vector issue rate for worlds that sit in cache or registers
+    (round 3 printed 1.10 of the HBM peak for cfg2).  A kernel change without a new counter pass fails here — by design."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rf = d["roofline"]
+    assert rf["bound_source"].startswith("counters: profiles/r") and f"_{workload}_traffic.json" in rf["bound_source"], rf["bound_source"]
+    assert rf["frac"] is not None and 0 < rf["frac"] <= 1.0, rf["frac"]
+    assert rf["valu_issue_frac"] is not None and rf["l2_hit_rate"] is not None and rf["traffic"] and rf["traffic"] > 0
+    if workload in ("cfg2", "cfg5", "demo"):   # in cache / in registers: vector issue, with the HBM-model figure beside it
+        assert rf["bound"] == "valu-issue" and rf["unit"] == "G wave-instructions/s" and rf["frac_hbm_model"] > 0
+    else:                                       # a million triangles: beyond the L2s, the SURVEY 8(d) model against the HBM peak
+        assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["frac_hbm_model"]) < 1e-9
+
+
 def test_dropin_cpp_api_renders(ctx):
     """camera::render(world, env, post, flag) of include/zenith/zenith.hpp end to end equals the C-ABI render — on the pipeline
     (mix0) and on the fused small-scene kernel (cfg5: the drop-in always passes render_flag and lines_rendered, so its frame comes
