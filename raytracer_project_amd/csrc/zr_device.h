@@ -60,7 +60,10 @@ struct Rng {
     __device__ __forceinline__ double range(double a, double b) { return a + (b - a) * next(); }
 };
 
-__device__ inline V3 random_unit_vector(Rng& g) {  // vec3.hpp:184-191
+// vec3.hpp:184-191.  (Round 4 tried letting the lanes that have their vector draw the pending lanes' next candidates — the wave runs this loop until its slowest
+// lane accepts, ~7 iterations at 1.9 per lane — through LDS tables: bit-identical, and no faster on any workload: profiles/r4_experiments_ab.txt,
+// scripts/dev/ruv_help_experiment.patch.  What did pay is ONE call site for all material kinds: scatter().)
+__device__ inline V3 random_unit_vector(Rng& g) {
     for (;;) {
         double x = g.range(-1, 1);
         double y = g.range(-1, 1);
@@ -681,11 +684,16 @@ __device__ inline V3 get_albedo(const DScene& sc, const Rec& rec) {
 __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec, V3& att, Ray& out, Rng& g) {
     if (rec.mat >= sc.n_mats) return false;
     const zr_material& m = sc.mats[rec.mat];
+    // lambertian, metal and the isotropic phase function each begin their draws with random_unit_vector() (material.hpp:82,141, constant_medium.hpp:15; bump maps draw
+    // nothing): taken HERE, once, for the lanes of all three kinds together — in a wave that mixes them (the fused kernel: walls, fog) the rejection sampler, which
+    // runs until its slowest lane accepts, used to run once per kind
+    V3 ruv = mk(0, 0, 0);
+    if (m.kind == ZR_MAT_LAMBERTIAN || m.kind == ZR_MAT_METAL || m.kind == ZR_MAT_ISOTROPIC) ruv = random_unit_vector(g);
     switch (m.kind) {
         case ZR_MAT_LAMBERTIAN: {  // material.hpp:74-96
             V3 wn = rec.n;
             if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
-            V3 dir = wn + random_unit_vector(g);
+            V3 dir = wn + ruv;
             if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = wn;
             out.o = rec.p + (rec.n * 0.0001);
             out.d = dir;
@@ -697,7 +705,7 @@ __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec,
             if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
             V3 v = unit(rin.d);
             V3 refl = reflect(v, wn);
-            V3 dir = unit(refl + (m.param * random_unit_vector(g)));
+            V3 dir = unit(refl + (m.param * ruv));
             out.o = rec.p + (0.0001 * rec.n);
             out.d = dir;
             att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
@@ -733,7 +741,7 @@ __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec,
         }
         case ZR_MAT_ISOTROPIC: {  // constant_medium.hpp:14-18
             out.o = rec.p;
-            out.d = random_unit_vector(g);
+            out.d = ruv;
             att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
             return true;
         }
@@ -786,8 +794,10 @@ __device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, con
     const zr_material& m = sc.mats[rec.mat];
     const uint32_t kind = m.kind;
     if (kind == ZR_MAT_LIGHT) { em = lean_color(sc, m.tex); return false; }
+    V3 ruv = mk(0, 0, 0);   // (one call site for both kinds that draw a unit vector first: see scatter())
+    if (kind == ZR_MAT_LAMBERTIAN || kind == ZR_MAT_METAL) ruv = random_unit_vector(g);
     if (kind == ZR_MAT_LAMBERTIAN) {  // material.hpp:74-96
-        V3 dir = rec.n + random_unit_vector(g);
+        V3 dir = rec.n + ruv;
         if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = rec.n;
         out.o = rec.p + (rec.n * 0.0001);
         out.d = dir;
@@ -797,7 +807,7 @@ __device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, con
     if (kind == ZR_MAT_METAL) {  // material.hpp:129-151
         V3 v = unit(rin.d);
         V3 refl = reflect(v, rec.n);
-        V3 dir = unit(refl + (m.param * random_unit_vector(g)));
+        V3 dir = unit(refl + (m.param * ruv));
         out.o = rec.p + (0.0001 * rec.n);
         out.d = dir;
         att = lean_color(sc, m.tex);
