@@ -216,6 +216,25 @@ __device__ __forceinline__ bool cube_t(const double* q, const Ray& r, double tmi
     return true;
 }
 
+// cube_t with 1 / d given: the caller computed it once for a ray that meets several cubes (the fused small-scene kernel: a Cornell box is seven of them, and a
+// translate leaves the direction alone, translate.hpp:15-22) — the same division on the same operand, so the same bits, 3 instead of 3 per cube
+__device__ __forceinline__ bool cube_t_inv(const double* q, const Ray& r, V3 inv_d, double tmin, double tmax, double& t) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double he = q[i];
+        double inv = get(inv_d, i);
+        double o = get(r.o, i);
+        double t0 = (-he - o) * inv;
+        double t1 = (he - o) * inv;
+        if (inv < 0.0) { double x = t0; t0 = t1; t1 = x; }
+        tmin = fmax(t0, tmin);
+        tmax = fmin(t1, tmax);
+        if (tmax < tmin) return false;
+    }
+    t = tmin;
+    return true;
+}
+
 // A placed cube: the ray goes through translate::hit's, rotate_y::hit's and scale::hit's first halves (translate.hpp:15-22, rotate_y.hpp:44-56,
 // scale.hpp:20-24) exactly as chain_ray would apply them, then cube::hit — the wrapper parameters come with the record instead of from an op list
 // SCALED = false: the caller knows that no record carries a scale (the fused small-scene kernel: the host sends worlds with scaled placed cubes
@@ -239,6 +258,13 @@ template <bool SCALED = true>
 __device__ __forceinline__ bool pcube_t(const double* q, const Ray& r, double tmin, double tmax, double& t) {
     const Ray lr = pcube_ray<SCALED>(q, r);
     return cube_t(q, lr, tmin, tmax, t);
+}
+// ... with the world ray's 1 / d given: used as it is when the record neither rotates nor scales (the direction is the world ray's)
+template <bool SCALED = true>
+__device__ __forceinline__ bool pcube_t_inv(const double* q, const Ray& r, V3 inv_d, double tmin, double tmax, double& t) {
+    const Ray lr = pcube_ray<SCALED>(q, r);
+    if (q[11] != 0.0 || (SCALED && q[15] != 0.0)) return cube_t(q, lr, tmin, tmax, t);
+    return cube_t_inv(q, lr, inv_d, tmin, tmax, t);
 }
 
 __device__ inline bool bare_t(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double tmin, double tmax, double& t) {
@@ -687,36 +713,35 @@ __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec,
     // lambertian, metal and the isotropic phase function each begin their draws with random_unit_vector() (material.hpp:82,141, constant_medium.hpp:15; bump maps draw
     // nothing): taken HERE, once, for the lanes of all three kinds together — in a wave that mixes them (the fused kernel: walls, fog) the rejection sampler, which
     // runs until its slowest lane accepts, used to run once per kind
-    V3 ruv = mk(0, 0, 0);
-    if (m.kind == ZR_MAT_LAMBERTIAN || m.kind == ZR_MAT_METAL || m.kind == ZR_MAT_ISOTROPIC) ruv = random_unit_vector(g);
+    // ... and the same for their albedo texture and bump map: one look-up site instead of three (neither draws)
+    V3 ruv = mk(0, 0, 0), tv = mk(0, 0, 0), wn = rec.n;
+    if (m.kind == ZR_MAT_LAMBERTIAN || m.kind == ZR_MAT_METAL || m.kind == ZR_MAT_ISOTROPIC) {
+        ruv = random_unit_vector(g);
+        tv = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+    }
+    if (m.kind <= ZR_MAT_DIELECTRIC && m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);   // lambertian, metal, dielectric
+    V3 ud = mk(0, 0, 0);   // unit_vector(r_in.direction()): metal and dielectric (material.hpp:139,199)
+    if (m.kind == ZR_MAT_METAL || m.kind == ZR_MAT_DIELECTRIC) ud = unit(rin.d);
     switch (m.kind) {
         case ZR_MAT_LAMBERTIAN: {  // material.hpp:74-96
-            V3 wn = rec.n;
-            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
             V3 dir = wn + ruv;
             if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = wn;
             out.o = rec.p + (rec.n * 0.0001);
             out.d = dir;
-            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            att = tv;
             return true;
         }
         case ZR_MAT_METAL: {  // material.hpp:129-151
-            V3 wn = rec.n;
-            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
-            V3 v = unit(rin.d);
-            V3 refl = reflect(v, wn);
+            V3 refl = reflect(ud, wn);
             V3 dir = unit(refl + (m.param * ruv));
             out.o = rec.p + (0.0001 * rec.n);
             out.d = dir;
-            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            att = tv;
             return dot(dir, rec.n) > 0;
         }
         case ZR_MAT_DIELECTRIC: {  // material.hpp:192-224, 237-241
             att = mk(m.tint[0], m.tint[1], m.tint[2]);
-            V3 wn = rec.n;
-            if (m.bump_tex != ZR_NO_TEXTURE) wn = bumped_normal(sc, rec, m.bump_tex, m.bump_strength);
             double ri = rec.front ? (1.0 / m.param) : m.param;
-            V3 ud = unit(rin.d);
             double ct = fmin(dot(-ud, wn), 1.0);
             double st = sqrt(1.0 - ct * ct);
             bool refl = ri * st > 1.0;
@@ -742,7 +767,7 @@ __device__ inline bool scatter(const DScene& sc, const Ray& rin, const Rec& rec,
         case ZR_MAT_ISOTROPIC: {  // constant_medium.hpp:14-18
             out.o = rec.p;
             out.d = ruv;
-            att = tex_value(sc, m.tex, rec.u, rec.v, rec.p);
+            att = tv;
             return true;
         }
         default: return false;  // diffuse_light, material.hpp:255-259
@@ -796,6 +821,8 @@ __device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, con
     if (kind == ZR_MAT_LIGHT) { em = lean_color(sc, m.tex); return false; }
     V3 ruv = mk(0, 0, 0);   // (one call site for both kinds that draw a unit vector first: see scatter())
     if (kind == ZR_MAT_LAMBERTIAN || kind == ZR_MAT_METAL) ruv = random_unit_vector(g);
+    V3 ud = mk(0, 0, 0);
+    if (kind == ZR_MAT_METAL || kind == ZR_MAT_DIELECTRIC) ud = unit(rin.d);
     if (kind == ZR_MAT_LAMBERTIAN) {  // material.hpp:74-96
         V3 dir = rec.n + ruv;
         if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = rec.n;
@@ -805,8 +832,7 @@ __device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, con
         return true;
     }
     if (kind == ZR_MAT_METAL) {  // material.hpp:129-151
-        V3 v = unit(rin.d);
-        V3 refl = reflect(v, rec.n);
+        V3 refl = reflect(ud, rec.n);
         V3 dir = unit(refl + (m.param * ruv));
         out.o = rec.p + (0.0001 * rec.n);
         out.d = dir;
@@ -816,7 +842,6 @@ __device__ __forceinline__ bool lean_shade(const DScene& sc, const Ray& rin, con
     if (kind == ZR_MAT_DIELECTRIC) {  // material.hpp:192-224, 237-241
         att = mk(m.tint[0], m.tint[1], m.tint[2]);
         double ri = rec.front ? (1.0 / m.param) : m.param;
-        V3 ud = unit(rin.d);
         double ct = fmin(dot(-ud, rec.n), 1.0);
         double st = sqrt(1.0 - ct * ct);
         bool refl = ri * st > 1.0;

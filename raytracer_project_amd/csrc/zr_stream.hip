@@ -903,6 +903,7 @@ __device__ __forceinline__ void brute_hit(const DScene& sc, const FusedObjs& fo,
     const double INF = __builtin_huge_val();
     tbest = INF; kbest = 0xFFFFFFFFu; ibest = 0;
     double t;
+    const V3 inv_d = mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);   // for the cubes that see the world ray's direction (cube_t_inv)
     // the table's objects: wave-uniform loop counter and kind, records through scalar loads
     for (uint32_t i = 0; i < fo.n; i++) {
         const uint32_t k = fo.kind[i];
@@ -910,8 +911,8 @@ __device__ __forceinline__ void brute_hit(const DScene& sc, const FusedObjs& fo,
         bool h;
         if (k == ZR_PRIM_SPHERE) h = sphere_t(q, ray, 0.001, tbest, t);
         else if (k == ZR_PRIM_TRIANGLE) h = triangle_t(q, ray, 0.001, tbest, t);
-        else if (k == ZR_PRIM_CUBE) h = cube_t(q, ray, 0.001, tbest, t);
-        else if (k == ZR_KIND_PCUBE) h = pcube_t<false>(q, ray, 0.001, tbest, t);   // (no scaled placed cube reaches this kernel: zr_commit.cpp finish_commit)
+        else if (k == ZR_PRIM_CUBE) h = cube_t_inv(q, ray, inv_d, 0.001, tbest, t);
+        else if (k == ZR_KIND_PCUBE) h = pcube_t_inv<false>(q, ray, inv_d, 0.001, tbest, t);   // (no scaled placed cube reaches this kernel: zr_commit.cpp finish_commit)
         else h = medium_rec_t(q, ray, 0.001, tbest, g, t);
         if (h) { tbest = t; kbest = k; ibest = fo.index[i]; }
         if (COUNT) { if (k == ZR_PRIM_SPHERE) cn[0]++; else if (k == ZR_PRIM_TRIANGLE) cn[1]++; else if (k == ZR_PRIM_CUBE || k == ZR_KIND_PCUBE) cn[2]++; else cn[3]++; }
