@@ -480,12 +480,26 @@ __device__ inline void triangle_rec(const DScene& sc, uint32_t idx, const Ray& r
     rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
 }
 
-__device__ inline void cube_rec_q(const double* q, uint32_t mat, const Ray& r, double t, Rec& rec) {  // cube.hpp:73-142
+// uv = false: u, v, tangent and bitangent are left zero — nothing reads them (the hit's material looks up no image and has no bump map: mat_needs_uv);
+// the face's u, v cost two divisions per hit, and a Cornell box is all cubes
+__device__ inline void cube_rec_q(const double* q, uint32_t mat, const Ray& r, double t, Rec& rec, bool uv = true) {  // cube.hpp:73-142
     V3 he = ld3(q), center = ld3(q + 3);
     rec.t = t;
     rec.p = at(r, t);
     V3 p = rec.p - center;
     const double EPS = 1e-3;
+    if (!uv) {
+        if (fabs(p.x + he.x) < EPS) rec.n = mk(-1, 0, 0);
+        else if (fabs(p.x - he.x) < EPS) rec.n = mk(1, 0, 0);
+        else if (fabs(p.y + he.y) < EPS) rec.n = mk(0, -1, 0);
+        else if (fabs(p.y - he.y) < EPS) rec.n = mk(0, 1, 0);
+        else if (fabs(p.z + he.z) < EPS) rec.n = mk(0, 0, -1);
+        else rec.n = mk(0, 0, 1);
+        rec.u = 0; rec.v = 0; rec.tan = mk(0, 0, 0); rec.bit = mk(0, 0, 0);
+        rec.mat = mat;
+        set_face(rec, r.d, rec.n);
+        return;
+    }
     if (fabs(p.x + he.x) < EPS) {
         rec.n = mk(-1, 0, 0); rec.u = (p.z + he.z) / (2 * he.z); rec.v = (p.y + he.y) / (2 * he.y); rec.tan = mk(0, 0, 1);
     } else if (fabs(p.x - he.x) < EPS) {
@@ -503,11 +517,14 @@ __device__ inline void cube_rec_q(const double* q, uint32_t mat, const Ray& r, d
     rec.mat = mat;
     set_face(rec, r.d, rec.n);
 }
-__device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec) { cube_rec_q(sc.cubes + (size_t)idx * 6, sc.cube_mat[idx], r, t, rec); }
+__device__ inline void cube_rec(const DScene& sc, uint32_t idx, const Ray& r, double t, Rec& rec, bool full = true) {
+    const uint32_t mat = sc.cube_mat[idx];
+    cube_rec_q(sc.cubes + (size_t)idx * 6, mat, r, t, rec, full || mat_needs_uv(sc, mat));
+}
 
 __device__ inline void bare_rec(const DScene& sc, uint32_t kind, uint32_t idx, const Ray& r, double t, Rec& rec, bool full) {
     if (kind == ZR_PRIM_SPHERE) sphere_rec(sc, idx, r, t, rec, full);
-    else if (kind == ZR_PRIM_CUBE) cube_rec(sc, idx, r, t, rec);
+    else if (kind == ZR_PRIM_CUBE) cube_rec(sc, idx, r, t, rec, full);
     else if (kind == ZR_PRIM_TRIANGLE) triangle_rec(sc, idx, r, t, rec);
     else {  // medium: constant_medium.hpp:70-75
         rec.t = t;
@@ -526,7 +543,7 @@ __device__ inline void object_rec(const DScene& sc, uint32_t kind, uint32_t idx,
     if (kind == ZR_KIND_PCUBE) {   // cube::hit's record in object space, then the second halves of scale::hit, rotate_y::hit and translate::hit, inside-out
         const double* q = sc.pcubes + (size_t)idx * ZR_PCUBE_STRIDE;
         const Ray lr = pcube_ray<PSCALE>(q, r);
-        cube_rec_q(q, sc.pcube_mat[idx], lr, t, rec);
+        cube_rec_q(q, sc.pcube_mat[idx], lr, t, rec, full || mat_needs_uv(sc, sc.pcube_mat[idx]));
         zr_xform_op op; op.mat = 0;
         if (PSCALE && q[15] != 0.0) { op.kind = ZR_OP_SCALE; op.a[0] = q[12]; op.a[1] = q[13]; op.a[2] = q[14]; apply_op_rec(op, r.d, rec); }   // scale.hpp:29-33 (reads no ray)
         if (q[11] != 0.0) { op.kind = ZR_OP_ROTATE_Y; op.a[0] = q[9]; op.a[1] = q[10]; op.a[2] = 0; apply_op_rec(op, r.d, rec); }   // the ray rotate_y received: translated only, same direction
