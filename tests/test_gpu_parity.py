@@ -580,7 +580,8 @@ def test_bench_line_contract(built):
                 "random_record_rate_G_per_s", "frac_random_records", "kernel", "kernel_ms", "launches_timed", "model"):
         assert key in rf, key
     # cfg1 is three spheres: the fused small-scene kernel renders it, and what bounds that kernel is FP64 vector issue, not HBM
-    assert rf["bound"] in ("fp64-valu", "l2-request-rate", "hbm") and rf["bound"] == "fp64-valu" and rf["kernel"] == "fused_render"
+    # ("valu-issue" when a counter pass of the current kernel source is committed: frac is then the measured share of the issue rate; "fp64-valu" by construction without one)
+    assert rf["bound"] in ("fp64-valu", "valu-issue") and rf["kernel"] == "fused_render"
     assert d["config"]["render_path"] == "fused small-scene kernel" and d["config"]["bvh_builder"].startswith(("host", "device"))
     assert d["config"]["bvh_build_upload_s"] >= 0 and d["config"]["bvh_build_upload_first_s"] >= 0
     # a register-resident kernel is not under the HBM ceiling: `frac` is its share of the chip's vector issue rate (from the counter file of the current kernel
