@@ -594,6 +594,35 @@ __global__ __launch_bounds__(256) void k_plan(const BNode* __restrict__ bn, cons
     }
 }
 
+// DETERMINISTIC QUAD NUMBERS.  k_plan hands out quad indices with an atomic counter: the frame does not depend on them, but the node array's layout — and
+// with it the cache behaviour of EXTEND, a few per cent of noise between two commits of the same scene — did.  After the plan the quads are renumbered by the id of the
+// binary node each one is rooted at, highest id first (ids are a pure function of the input; a parent's id is above its children's, so the order is top-down): an
+// exclusive scan over "is a quad root" along descending ids gives the new number, the records move there with their inner references rewritten.
+struct QRootFlag {
+    const uint32_t* qroot; uint32_t top;
+    __host__ __device__ uint32_t operator()(uint32_t k) const { return qroot[top - k] != 0xFFFFFFFFu ? 1u : 0u; }
+};
+__global__ __launch_bounds__(256) void k_qmap(uint32_t* __restrict__ qroot, const uint32_t* __restrict__ qscan, uint32_t n_nodes, uint32_t* __restrict__ qmap) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_nodes) return;
+    const uint32_t id = n_nodes - 1 - k, old = qroot[id];
+    if (old == NONE) return;
+    qmap[old] = qscan[k];
+    qroot[id] = qscan[k];
+}
+__global__ __launch_bounds__(256) void k_qpermute(const NodeQ* __restrict__ src, NodeQ* __restrict__ dst, const uint32_t* __restrict__ qinst_src, uint32_t* __restrict__ qinst_dst,
+                                                  const uint32_t* __restrict__ qmap, uint32_t cap, PlanOut* __restrict__ po) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q == 0)   // the FP32 root's references (unused when the root is a stored node)
+        for (int c = 0; c < 4; c++) { const uint32_t r = po->root.ref[c]; if (r != ZR_REF_EMPTY && !(r & ZR_REF_LEAF) && r < cap) po->root.ref[c] = qmap[r]; }
+    if (q >= po->counter || q >= cap) return;
+    NodeQ nq = src[q];
+    for (int c = 0; c < 4; c++) { const uint32_t r = nq.ref[c]; if (r != ZR_REF_EMPTY && !(r & ZR_REF_LEAF)) nq.ref[c] = qmap[r]; }
+    const uint32_t to = qmap[q];
+    dst[to] = nq;
+    qinst_dst[to] = qinst_src[q];
+}
+
 // forward over the batches (children before parents): demand(node) = max(nk, nk - 1 + max over inner children of their demand,
 // nk - 1 + an instance leaf's 1 + its group's demand)  — Flattener::demand_of
 __device__ __forceinline__ uint32_t demand_from(const uint32_t refs[4], uint32_t inst_demand, const uint32_t* __restrict__ qdem) {
@@ -824,6 +853,7 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     PBox* pbox; uint64_t *keys_a, *keys_b; uint32_t *vals_a, *vals_b; Cl *cl_a, *cl_b; BNode* bn;
     uint32_t *parent, *ncount, *nmeta, *leaf_pos, *qroot, *nn, *blk_keep, *blk_new, *keep_off, *new_off, *dfs_obj, *rank, *scanned, *qlevel, *qinst, *qdem, *compound, *state;
     float* ncost; uint8_t *act, *dfs_kind; PlanOut* po; void* tmp; size_t tmp_bytes = 0;
+    uint32_t *qinst_plan, *qmap, *qscan; NodeQ* quads_plan;
     auto layout = [&](unsigned char* base) -> size_t {
         unsigned char* at = base;
         auto take = [&](size_t bytes) { void* p = at; at += (bytes + 255) / 256 * 256; return p; };
@@ -841,6 +871,8 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
         dfs_obj = (uint32_t*)take((size_t)n * 4); dfs_kind = (uint8_t*)take(n);
         rank = (uint32_t*)take((size_t)n * 4); scanned = (uint32_t*)take((size_t)n * 4);
         qlevel = (uint32_t*)take((size_t)n * 4); qinst = (uint32_t*)take((size_t)n * 4); qdem = (uint32_t*)take((size_t)n * 4);
+        qinst_plan = (uint32_t*)take((size_t)n * 4); qmap = (uint32_t*)take((size_t)n * 4); qscan = (uint32_t*)take(N * 4);
+        quads_plan = (NodeQ*)take((size_t)n * sizeof(NodeQ));   // the plan's records under the atomic counter's numbers, before k_qpermute
         compound = (uint32_t*)take((size_t)n * 8);
         state = (uint32_t*)take(256);        // [0] survivors, [1] new nodes; [8..14] bounds; [16] max depth, [17] final leaves; [20] compound count
         po = (PlanOut*)take(sizeof(PlanOut));
@@ -850,6 +882,10 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
             (void)rocprim::exclusive_scan(nullptr, b, rocprim::make_transform_iterator(dfs_kind, IsKind{0}), scanned, 0u, (size_t)n, rocprim::plus<uint32_t>(), st_);
             (void)rocprim::exclusive_scan(nullptr, c, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), InnerFlag{nmeta, 0}), scanned, 0u,
                                           (size_t)n, rocprim::plus<uint32_t>(), st_);
+            size_t d = 0;
+            (void)rocprim::exclusive_scan(nullptr, d, rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), QRootFlag{qroot, 0}), qscan, 0u, N,
+                                          rocprim::plus<uint32_t>(), st_);
+            if (d > c) c = d;
             tmp_bytes = (a > b ? (a > c ? a : c) : (b > c ? b : c)) + 4096;
         }
         tmp = take(tmp_bytes);
@@ -995,22 +1031,33 @@ hipError_t DeviceBuilder::build(const BuildSceneIn& in, const zr_object* d_objec
     PlanOut h_po_in; std::memset(&h_po_in, 0, sizeof h_po_in);   // (source of an asynchronous copy: not written again before the next synchronisation)
     h_po_in.counter = root_in_array ? 1u : 0u;
     if ((e = hipMemcpyAsync(po, &h_po_in, sizeof h_po_in, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(qinst_plan, 0, (size_t)n * 4, st_)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(qinst, 0, (size_t)n * 4, st_)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(qdem, 0, (size_t)n * 4, st_)) != hipSuccess) return e;
+    auto renumber = [&]() -> hipError_t {   // see k_qmap
+        auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), QRootFlag{qroot, root});
+        hipError_t er = rocprim::exclusive_scan(tmp, tmp_bytes, flags, qscan, 0u, (size_t)n_nodes, rocprim::plus<uint32_t>(), st_);
+        if (er != hipSuccess) { err_ = "scan failed"; return er; }
+        hipLaunchKernelGGL(k_qmap, grid_for(n_nodes), dim3(256), 0, st_, qroot, qscan, n_nodes, qmap);
+        hipLaunchKernelGGL(k_qpermute, grid_for(quad_cap), dim3(256), 0, st_, quads_plan, quads, qinst_plan, qinst, qmap, quad_cap, po);
+        return hipSuccess;
+    };
     if (root_in_array) {   // the root is quad 0, level 0
         if ((e = hipMemsetAsync(qroot + root, 0, 4, st_)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(qlevel, 0, 4, st_)) != hipSuccess) return e;
     }
     if (n == 1) {   // a single primitive: the "batch" is the primitive itself
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, st_, bn, nmeta, ncount, leaf_pos, root, root + 1, root, root_in_array ? 1 : 0, prm.open_ratio, d_objects, d_run_demand,
-                           qroot, qlevel, qinst, quads, po);
+                           qroot, qlevel, qinst_plan, quads_plan, po);
+        if ((e = renumber()) != hipSuccess) return e;
         hipLaunchKernelGGL(k_demand, dim3(1), dim3(256), 0, st_, qroot, root, root + 1, root, root_in_array ? 1 : 0, quads, qinst, qdem, po);
     } else {
         for (size_t b = batch_start.size() - 1; b-- > 0;) {
             const uint32_t lo = batch_start[b], hi = batch_start[b + 1];
             hipLaunchKernelGGL(k_plan, grid_for(hi - lo), dim3(256), 0, st_, bn, nmeta, ncount, leaf_pos, lo, hi, root, root_in_array ? 1 : 0, prm.open_ratio, d_objects,
-                               d_run_demand, qroot, qlevel, qinst, quads, po);
+                               d_run_demand, qroot, qlevel, qinst_plan, quads_plan, po);
         }
+        if ((e = renumber()) != hipSuccess) return e;
         for (size_t b = 0; b + 1 < batch_start.size(); b++) {
             const uint32_t lo = batch_start[b], hi = batch_start[b + 1];
             hipLaunchKernelGGL(k_demand, grid_for(hi - lo), dim3(256), 0, st_, qroot, lo, hi, root, root_in_array ? 1 : 0, quads, qinst, qdem, po);

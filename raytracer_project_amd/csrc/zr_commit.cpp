@@ -99,6 +99,17 @@ int finish_commit(zr_scene* s, const CommitSummary& cs, size_t n_objs) {
     s->stats[3] = cs.n_pairs * sizeof(zr::NodePair) + cs.n_quads * sizeof(zr::NodeQ) + (cs.n_sph * 4 + cs.n_tri * (ZR_TRI_STRIDE + 20) + cs.n_cube * 6 + cs.n_pcube * ZR_PCUBE_STRIDE) * 8 +
                   (cs.n_sph + cs.n_cube) * 4 + s->texels.size();
     s->builder = cs.builder;
+    if (std::getenv("ZR_COMMIT_HASH")) {   // development / test aid: a hash of the committed 4-wide node array and pair records — the tree AND its layout in memory
+        (void)hipDeviceSynchronize();
+        auto fnv = [](const void* dev, size_t bytes) -> unsigned long long {
+            std::vector<unsigned char> h(bytes);
+            unsigned long long x = 1469598103934665603ull;
+            if (bytes && hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) == hipSuccess) for (unsigned char b : h) { x ^= b; x *= 1099511628211ull; }
+            return x;
+        };
+        std::fprintf(stderr, "[zr] commit hash (%s): quads %016llx (%zu), pairs %016llx (%zu)\n", cs.builder, fnv(s->d_quads.p, cs.n_quads * sizeof(zr::NodeQ)), cs.n_quads,
+                     fnv(s->d_nodes.p, cs.n_pairs * sizeof(zr::NodePair)), cs.n_pairs);
+    }
     s->committed = true;
     if (s->borrowed) {   // the caller's arrays are not read again: forget them (a second commit needs a new zr_scene_set_*)
         s->spheres.drop(); s->sphere_mat.drop(); s->tri_v.drop(); s->tri_n.drop(); s->tri_mat.drop(); s->cubes.drop(); s->cube_mat.drop();

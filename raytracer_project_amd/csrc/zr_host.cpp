@@ -40,7 +40,7 @@ zr_ctx* zr_create(int device_ordinal) {
         if ((e = hipStreamCreateWithFlags(&c->sub[k], hipStreamNonBlocking)) != hipSuccess) {
             fail(ZR_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr;
         }
-    if (c->d_ctr.alloc(16) != ZR_OK) { delete c; return nullptr; }
+    if (c->d_ctr.alloc(48) != ZR_OK)   /* 16 counter words + 32 for development builds (ZR_WAVE_PROFILE: per-phase lane histograms) */ { delete c; return nullptr; }
     c->variant = (int)env_double("ZR_KERNEL", 2);
     if (c->variant != 2) c->variant = 0;   // (variant 1, the round-1 wave-scheduler megakernel, is retired: 2-6 x slower and nothing depended on it)
     c->log_kind = (int)env_double("ZR_TIMELOG_KIND", 1);

@@ -157,7 +157,7 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     const uint32_t n_pix = (uint32_t)c->d_pixels.n;
     if (c->pending.size() > 65536) { int rr = resolve_times(c); if (rr) return rr; }
     c->render_id++; c->last_stream = stream; c->last_counted = count != 0; c->last_rounds = 0;
-    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 48 * sizeof(unsigned long long), stream));
     if (n_pix == 0) return ZR_OK;
     const uint32_t spp = (uint32_t)dc.spp;
     const uint64_t units = (uint64_t)n_pix * spp;   // one work unit per primary sample
@@ -271,7 +271,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
     std::vector<int32_t> tiles = plan.tiles;
     int rc = c->d_tiles.upload(tiles);
     if (rc) return rc;
-    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+    HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 48 * sizeof(unsigned long long), stream));
     // the streaming pipeline packs bounce counters into 8 bits, work units into 32 bits and leaf references into 24 + 4
     // bits; frames or scenes beyond that are rendered by the pixel-group megakernel below (slower, same results)
     uint64_t stream_units = 0;
@@ -287,7 +287,7 @@ int enqueue_render(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const zr_
         // the pipeline's buffers (24 bytes per primary sample + the slot pool) do not fit beside what else lives on the device: the
         // pixel-group kernel below needs neither
         std::fprintf(stderr, "[zr] %s: rendering this frame with the pixel-group kernel (same results, slower)\n", zr_host::last_error());
-        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), stream));
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 48 * sizeof(unsigned long long), stream));
     } else if (c->variant == 2 && !c->warned_fallback) {   // said once per context: the frame is rendered, by the slower kernel
         c->warned_fallback = true;
         std::fprintf(stderr, "[zr] frame outside the streaming pipeline's packing limits (max_depth %d > 250, %llu work units > 2^32, %d x %d px > 65535, "
@@ -519,7 +519,7 @@ int zr_render_passes(zr_ctx* c, const zr_scene* s, const zr_camera* cam, const z
         c->last_counted = true;
     } else {
         c->render_id++; c->last_counted = true; c->last_rounds = 0;
-        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 48 * sizeof(unsigned long long), c->stream));
         HIP_OK(zr::launch_passes(s->ds, dc, de, seed, wd, d_b.p, d_r.p, d_f.p, c->d_ctr.p, c->stream));
     }
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -619,6 +619,18 @@ int zr_get_counters(zr_ctx* c, zr_counters* out) {
         out->triangles_tested = h[4]; out->cubes_tested = h[5]; out->media_tested = h[6]; out->hits = h[7]; out->rng_draws = h[8];
         out->node_execs = h[9]; out->node_lanes = h[10]; out->leaf_execs = h[11]; out->leaf_lanes = h[12]; out->shade_execs = h[13]; out->shade_lanes = h[14];
     }
+    if (std::getenv("ZR_LANE_HISTOGRAM")) {   // development aid (a -DZR_WAVE_PROFILE build fills them): EXTEND's iterations per phase by ready lanes, 8 buckets of 8 lanes
+        unsigned long long hh[24];
+        HIP_OK(hipMemcpy(hh, c->d_ctr.p + 16, sizeof hh, hipMemcpyDeviceToHost));
+        const char* names[3] = {"NODE", "LEAF", "FETCH"};
+        for (int ph = 0; ph < 3; ph++) {
+            unsigned long long tot = 0;
+            for (int b = 0; b < 8; b++) tot += hh[ph * 8 + b];
+            std::fprintf(stderr, "[zr] %-5s iterations by ready lanes (1-8 ... 57-64):", names[ph]);
+            for (int b = 0; b < 8; b++) std::fprintf(stderr, " %5.1f%%", tot ? 100.0 * (double)hh[ph * 8 + b] / (double)tot : 0.0);
+            std::fprintf(stderr, "   of %llu\n", tot);
+        }
+    }
     return ZR_OK;
 }
 
@@ -655,7 +667,7 @@ int zr_trace(zr_ctx* c, const zr_scene* s, const double* rays6, size_t n, double
         DevBuf<unsigned char> pool;
         if ((rc = ensure_stack_slabs(c, s))) return rc;
         if ((rc = pool.alloc(zr::stream_pool_bytes((uint32_t)n) + 65536))) return rc;
-        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_OK(hipMemsetAsync(c->d_ctr.p, 0, 48 * sizeof(unsigned long long), c->stream));
         HIP_OK(zr::stream_trace(s->ds, d_rays.p, (uint32_t)n, seed, pixel, bounce, d_hits.p, pool.p, c->d_ctl.p, c->d_st_overflow.p, c->st_ovf_levels, c->st_blocks,
                                 c->d_ctr.p, s->leaf_level, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));

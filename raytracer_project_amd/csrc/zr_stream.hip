@@ -323,6 +323,9 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
 #ifdef ZR_WAVE_PROFILE
     const unsigned long long t_begin = wall_clock64();
     unsigned long long p_exec[3] = {0, 0, 0}, p_lanes[3] = {0, 0, 0};
+    // per-phase lane histogram: iterations of NODE / LEAF / FETCH by the number of lanes the phase ran with, in eight buckets of eight lanes
+    __shared__ unsigned int p_hist[ST_EXT_GROUP][24];
+    if (lane < 24) p_hist[threadIdx.x >> 6][lane] = 0;
 #endif
     for (; iter < iter_cap; iter++) {
         const uint32_t lkind = (cur >> 28) & 7u;
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
             uint32_t n = (uint32_t)__popcll(idle);
 #ifdef ZR_WAVE_PROFILE
             p_exec[2]++; p_lanes[2] += n;
+            if (lane == 0 && n > 0) p_hist[threadIdx.x >> 6][16 + ((n - 1) >> 3)]++;
 #endif
             while (chunk_next >= chunk_end && work_left) {
                 // reserve the next chunk of this wave's shard; an exhausted shard sends the wave to the next one
@@ -402,6 +406,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
             if (COUNT) { s_exec[0]++; s_lanes[0] += n1; }
 #ifdef ZR_WAVE_PROFILE
             p_exec[0]++; p_lanes[0] += n1;
+            if (lane == 0 && n1 > 0) p_hist[threadIdx.x >> 6][(n1 - 1) >> 3]++;
 #endif
             if (st == X_NODE) {
                 float tn0, tn1, tn2, tn3;
@@ -484,6 +489,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
             if (COUNT) { s_exec[1]++; s_lanes[1] += n2; }
 #ifdef ZR_WAVE_PROFILE
             p_exec[1]++; p_lanes[1] += n2;
+            if (lane == 0 && n2 > 0) p_hist[threadIdx.x >> 6][8 + ((n2 - 1) >> 3)]++;
 #endif
             const bool is_leaf = st == X_LEAF;
 #ifdef ST_LEAF_ALL
@@ -569,6 +575,7 @@ __global__ __launch_bounds__(64 * ST_EXT_GROUP, LEVEL >= 2 ? ST_EXT_WAVES : (LEV
     if (!COUNT && lane == 0) {  // development build: wave lifetime (10 ns ticks) and phase statistics into the raw counter words
         atomicAdd(&gctr[13], wall_clock64() - t_begin); atomicAdd(&gctr[14], 1ull);
         for (int k = 0; k < 3; k++) { atomicAdd(&gctr[1 + 2 * k], p_exec[k]); atomicAdd(&gctr[2 + 2 * k], p_lanes[k]); }
+        for (int k = 0; k < 24; k++) if (p_hist[threadIdx.x >> 6][k]) atomicAdd(&gctr[16 + k], (unsigned long long)p_hist[threadIdx.x >> 6][k]);   // (the context's counter block has 48 words)
     }
 #endif
     if (COUNT) {
