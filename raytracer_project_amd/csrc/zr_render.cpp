@@ -199,7 +199,10 @@ int render_stream(zr_ctx* c, const zr_scene* s, const zr::DCamera& dc, const zr:
     size_t drain_at = 0;
     for (uint32_t cap = c->st_slots;; cap /= 2) {
         P = cap / 64 * 64;
-        uint64_t want = std::max<uint64_t>(units / (uint64_t)std::max(1.0, env_double("ZR_STREAM_UNITS_PER_SLOT", 8)), 1u << 20);
+        // slots = units / 8 where the lean kernels run as two sub-pools (cfg2: 93.2 ms at 8, 98.9 at 4, 115 at 2), units / 3 for one pool of the general builds, whose
+        // launches are worth making larger (demo: 128.1 ms at 8, 126.0 at 4, 125.1 at 3: profiles/r4_experiments_ab.txt)
+        const bool lean_two_pools = s->leaf_level == 0 && s->ds.shade_lean != 0 && mode == 0;
+        uint64_t want = std::max<uint64_t>(units / (uint64_t)std::max(1.0, env_double("ZR_STREAM_UNITS_PER_SLOT", lean_two_pools ? 8 : 3)), 1u << 20);
         want = want / 64 * 64;
         if (want < P) P = (uint32_t)want;
         if (units < P) P = (uint32_t)((units + 63) / 64 * 64);
