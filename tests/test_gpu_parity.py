@@ -651,7 +651,7 @@ def test_dropin_cpp_api_renders(ctx):
     a, ctr = ds.render_dropin(spp=8)
     cam = ds.camera.copy(); cam.samples_per_pixel = 8
     b = gpu_scene(ctx, "cfg5").render(cam, ds.env, ds.seed, None)
-    assert ctr.path == 3 and np.array_equal(a, b)
+    assert ctr.path == (2 if os.environ.get("ZR_FUSED") == "0" else 3) and np.array_equal(a, b)   # (ZR_FUSED=0: the suite's sweep of non-default settings)
 
 
 def test_dropin_renders_from_successive_threads_share_one_context(ctx):
