@@ -619,6 +619,30 @@ def test_bench_line_names_its_bound_from_counters(built, workload):
         assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["frac_hbm_model"]) < 1e-9
 
 
+def test_lean_shade_build_renders_the_general_builds_image(ctx, monkeypatch):
+    """SHADE's lean build (zr_device.h lean_rec / lean_shade: worlds of bare triangles and spheres over solid-colour lambertian / metal / dielectric / light
+    materials, chosen at commit) leaves code out, not arithmetic: the frame equals the general build's — bit for bit on cfg3 (lambertian) and the instanced-free
+    sphere scene cfg2 at reduced size except where a dielectric's Schlick weight is involved (x^5 by three multiplications instead of pow: within 1e-12),
+    and the two sub-pools the lean pair runs on change nothing either."""
+    from raytracer_project_amd import capi
+    for name, args, spp, exact in (("cfg3", (200, 20, 256, 128), 16, True), ("cfg2", (), 4, False)):
+        ds = demo_scene(name, args)
+        cam = ds.camera.copy(); cam.samples_per_pixel = spp
+        reg = capi.Region(0, 0, 640, 360, 0, 0, 0, 0) if name == "cfg2" else None
+        frames = {}
+        for lean in ("1", "0"):
+            monkeypatch.setenv("ZR_SHADE_LEAN", lean)
+            sc = capi.Scene(ctx, ds.desc)
+            frames[lean] = sc.render(cam, ds.env, ds.seed, reg)
+            sc.close()
+        monkeypatch.delenv("ZR_SHADE_LEAN")
+        if exact:
+            assert np.array_equal(frames["1"], frames["0"]), name
+        else:
+            assert rel_err(frames["1"], frames["0"], 1e-6).max() < 1e-9, name
+        assert float(frames["1"].sum()) > 0
+
+
 def test_device_builder_lays_the_tree_out_the_same_way_every_time(built):
     """the device builder numbered its 4-wide nodes with an atomic counter — same tree, same frame, but a node array whose layout changed from commit
     to commit (cache behaviour, a few per cent of timing noise).  Quads are now renumbered by the binary node they are rooted at (zr_build.hip: k_qmap): the committed
